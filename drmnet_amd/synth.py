@@ -1,0 +1,82 @@
+"""Seeded synthetic weights and inputs (no checkpoints exist offline).
+
+The pretrained ``drmnet.ckpt`` / ``obsnet.ckpt`` are external downloads
+(reference README.md:48) and are unreachable here, and a fresh-init network
+outputs exactly zero because the reference zero-initialises the last conv of
+every ResBlock / AttentionBlock / head (openaimodel.py:229-231,314,706,927).
+So benches, tests and golden fixtures all use the same rule-based weights,
+drawn from one CPU ``torch.Generator`` per network, consumed in
+``state_dict()`` order:
+
+* ``ndim >= 2``      -> ``randn(shape) / sqrt(fan_in)``  (fan_in = prod(shape[1:]))
+* 1-D ``*.weight``   -> ``1 + 0.1 * randn``              (GroupNorm gamma)
+* 1-D ``*.bias``     -> ``0.1 * randn``
+
+torch's CPU generator is deterministic for a fixed torch version, so the GPU
+box regenerates bit-identical tensors from (ordered keys, shapes, seed).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import torch
+
+SEED_ILLNET = 1
+SEED_REFNET = 2
+SEED_OBSNET = 3
+SEED_ZEMB = 4
+SEED_INPUT = 1234
+
+
+def synth_tensor(name: str, shape: Sequence[int], gen: torch.Generator) -> torch.Tensor:
+    shape = tuple(int(s) for s in shape)
+    if len(shape) >= 2:
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        return torch.randn(shape, generator=gen, dtype=torch.float32) / math.sqrt(fan_in)
+    if name.endswith("weight"):
+        return 1.0 + 0.1 * torch.randn(shape, generator=gen, dtype=torch.float32)
+    return 0.1 * torch.randn(shape, generator=gen, dtype=torch.float32)
+
+
+def synth_state_dict(manifest: Iterable[Tuple[str, Sequence[int]]], seed: int) -> Dict[str, torch.Tensor]:
+    """manifest: ordered (key, shape) pairs in ``state_dict()`` order."""
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(int(seed))
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in manifest:
+        out[name] = synth_tensor(name, shape, gen)
+    return out
+
+
+def manifest_of(module: torch.nn.Module) -> List[Tuple[str, Tuple[int, ...]]]:
+    return [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+
+
+def load_synth(module: torch.nn.Module, seed: int) -> None:
+    sd = synth_state_dict(manifest_of(module), seed)
+    module.load_state_dict(sd, strict=True)
+
+
+def synth_refmaps(n: int, h: int, w: int, seed: int = SEED_INPUT) -> torch.Tensor:
+    """Synthetic HDR reflectance maps in network ("log") space, [n,3,h,w] fp32.
+
+    L = exp(N(-2, 1.5^2)) per pixel, box-blurred, luminance-normalised to a
+    geometric mean of 0.12 (as DRMNet.get_input_for_predict, drmnet.py:1020-1026),
+    then x = log10(L + 0.1) + 1 (BaseDataset "log", basedataset.py:52-53).
+    """
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(int(seed))
+    L = torch.exp(torch.randn((n, 3, h, w), generator=gen) * 1.5 - 2.0)
+    L = torch.nn.functional.avg_pool2d(L, 5, stride=1, padding=2, count_include_pad=False)
+    lum = 0.212671 * L[:, 0] + 0.715160 * L[:, 1] + 0.072169 * L[:, 2]
+    scale = 0.12 / torch.exp(torch.log(lum.clip(1e-5)).mean(dim=(1, 2)))
+    L = L * scale[:, None, None, None]
+    return (torch.log10(L + 0.1) + 1.0).contiguous()
+
+
+def checksum(t: torch.Tensor) -> float:
+    """Order-independent fp64 checksum used to pin regenerated tensors."""
+    return float(t.double().abs().sum().item())

@@ -1,0 +1,215 @@
+"""Pins the CPU oracle against every golden vector generated from the reference (CPU, no GPU).
+
+Fixtures: tests/golden/*.npz written by tools/make_golden.py (reference imported in the
+build container).  Tolerances are fp32 re-association noise only (the reference itself
+moves by ~5e-7 rel-L2 between 1 and 8 CPU threads).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold, rel_l2
+from drmnet_amd import synth
+from oracle import samplers as osamp
+from oracle import unet as ou
+
+TOL = 2e-5  # rel-L2, fp32 CPU vs fp32 CPU (different op decomposition)
+
+
+def params(cfg, kind, seed):
+    return synth.synth_state_dict(ou.param_manifest(cfg, kind), seed)
+
+
+@pytest.mark.parametrize(
+    "name,cfg,kind",
+    [
+        ("illnet", ou.ILLNET_CFG, "unet"),
+        ("refnet", ou.REFNET_CFG, "encoder"),
+        ("obsnet", ou.OBSNET_CFG, "unet"),
+        ("tiny_unet", ou.TINY_UNET_CFG, "unet"),
+        ("tiny_enc", ou.TINY_ENC_CFG, "encoder"),
+    ],
+)
+def test_manifest_matches_reference_state_dict(manifests, name, cfg, kind):
+    mine = [[k, list(s)] for k, s in ou.param_manifest(cfg, kind)]
+    assert mine == manifests[name]
+
+
+def test_timestep_embedding():
+    g = gold("timestep_embedding")
+    e = ou.timestep_embedding(torch.from_numpy(g["t"]), 128)
+    assert torch.equal(e, torch.from_numpy(g["emb"]))
+
+
+def test_ddpm_schedule_tables():
+    g = gold("ddpm_schedule")
+    s = osamp.ddpm_schedule(1000, 1e-4, 0.09)
+    for k, v in g.items():
+        assert np.array_equal(s[k].numpy(), v), k
+
+
+@pytest.mark.parametrize("eta", [0, 1])
+def test_ddim_schedule_tables(eta):
+    g = gold(f"ddim_schedule_eta{eta}")
+    s = osamp.ddpm_schedule(1000, 1e-4, 0.09)
+    d = osamp.ddim_schedule(s["alphas_cumprod"], 1000, 50, float(eta))
+    assert np.array_equal(d["ddim_timesteps"], g["timesteps"])
+    coef = osamp.ddim_step_coeffs(d)
+    assert np.array_equal(coef, g["coef"])
+
+
+def test_brdf_schedule_and_convergence():
+    g = gold("brdf_schedule")
+    z_out, z0 = torch.from_numpy(g["z_out"]), torch.from_numpy(g["z0"])
+    gamma, eps = float(g["gamma"]), float(g["epsilon"])
+    for i in (0, 1, 7, 50, 90, 149):
+        zk, zK = osamp.brdf_schedule(z_out, z0, gamma, i)
+        assert torch.equal(zk, torch.from_numpy(g[f"zk_{i}"])), i
+        assert torch.equal(osamp.check_convergence(zk, z0, eps), torch.from_numpy(g[f"conv_{i}"])), i
+        assert torch.equal(zK, torch.from_numpy(g["zK"]))
+
+
+@pytest.mark.parametrize("tag", ["16x16", "16x32"])
+def test_tiny_unet(tag):
+    g = gold(f"tiny_unet_{tag}")
+    P = params(ou.TINY_UNET_CFG, "unet", int(g["seed"]))
+    topo = ou.build_topology(ou.TINY_UNET_CFG, "unet")
+    x = torch.from_numpy(g["x"])
+    assert rel_l2(ou.unet_forward(P, topo, x, timesteps=torch.from_numpy(g["t"])), g["out_t"]) < TOL
+    assert rel_l2(ou.unet_forward(P, topo, x, t_emb=torch.from_numpy(g["t_emb"])), g["out_temb"]) < TOL
+    with pytest.raises(ValueError):
+        ou.unet_forward(P, topo, x)
+
+
+@pytest.mark.parametrize("tag", ["16x16", "16x32"])
+def test_tiny_encoder(tag):
+    g = gold(f"tiny_enc_{tag}")
+    P = params(ou.TINY_ENC_CFG, "encoder", int(g["seed"]))
+    topo = ou.build_topology(ou.TINY_ENC_CFG, "encoder")
+    out = ou.encoder_forward(P, topo, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
+    assert rel_l2(out, g["out"]) < TOL
+
+
+def block_inputs(a, b, h, w, n):
+    gen = torch.Generator().manual_seed(1000 + a + 7 * b + 13 * h + 17 * w)
+    emb = torch.randn((n, 512), generator=gen)
+    x = torch.randn((n, a, h, w), generator=gen)
+    return x, emb
+
+
+def resblock_manifest(cin, cout):
+    m = [("in_layers.0.weight", (cin,)), ("in_layers.0.bias", (cin,)), ("in_layers.2.weight", (cout, cin, 3, 3)), ("in_layers.2.bias", (cout,)),
+         ("emb_layers.1.weight", (cout, 512)), ("emb_layers.1.bias", (cout,)), ("out_layers.0.weight", (cout,)), ("out_layers.0.bias", (cout,)),
+         ("out_layers.3.weight", (cout, cout, 3, 3)), ("out_layers.3.bias", (cout,))]
+    if cin != cout:
+        m += [("skip_connection.weight", (cout, cin, 1, 1)), ("skip_connection.bias", (cout,))]
+    return m
+
+
+def attn_manifest(ch):
+    return [("norm.weight", (ch,)), ("norm.bias", (ch,)), ("qkv.weight", (3 * ch, ch, 1)), ("qkv.bias", (3 * ch,)),
+            ("proj_out.weight", (ch, ch, 1)), ("proj_out.bias", (ch,))]
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(256, 128, 16), (128, 128, 16), (1536, 768, 4)])
+def test_resblock(cin, cout, hw):
+    g = gold(f"resblock_{cin}_{cout}_{hw}")
+    n = int(g["n"])
+    x, emb = block_inputs(cin, cout, hw, hw, n)
+    assert synth.checksum(x) == pytest.approx(float(g["xsum"]), rel=1e-12)
+    P = {"rb." + k: v for k, v in synth.synth_state_dict(resblock_manifest(cin, cout), int(g["seed"])).items()}
+    out = ou.res_block(P, ou.Res("rb", cin, cout), x, emb)
+    assert rel_l2(out, g["out"]) < TOL
+
+
+@pytest.mark.parametrize("ch,h,w", [(512, 16, 16), (384, 32, 32), (768, 4, 8)])
+def test_attention_block(ch, h, w):
+    g = gold(f"attnblock_{ch}_{h}x{w}")
+    x, _ = block_inputs(ch, ch, h, w, int(g["n"]))
+    assert synth.checksum(x) == pytest.approx(float(g["xsum"]), rel=1e-12)
+    P = {"ab." + k: v for k, v in synth.synth_state_dict(attn_manifest(ch), int(g["seed"])).items()}
+    out = ou.attention_block(P, ou.Attn("ab", ch), x)
+    assert rel_l2(out, g["out"]) < TOL
+
+
+def full_inputs(n, h, w):
+    x = synth.synth_refmaps(n, h, w, synth.SEED_INPUT)
+    gen = torch.Generator().manual_seed(synth.SEED_INPUT + 1)
+    xk = x + 0.025 * torch.randn(x.shape, generator=gen)
+    t_emb = torch.randn((n, 128), generator=gen)
+    return torch.cat([xk, x], dim=1).contiguous(), t_emb
+
+
+@pytest.mark.parametrize("name,cfg,kind", [("illnet", ou.ILLNET_CFG, "unet"), ("refnet", ou.REFNET_CFG, "encoder"), ("obsnet", ou.OBSNET_CFG, "unet")])
+@pytest.mark.parametrize("n,h,w", [(2, 128, 128), (1, 128, 256)])
+def test_full_width_nets(name, cfg, kind, n, h, w):
+    g = gold(f"full_{name}_{h}x{w}")
+    P = params(cfg, kind, int(g["seed"]))
+    topo = ou.build_topology(cfg, kind)
+    xc, t_emb = full_inputs(n, h, w)
+    assert synth.checksum(xc) == pytest.approx(float(g["xsum"]), rel=1e-12)
+    t = torch.from_numpy(g["t"])
+    if name == "illnet":
+        out = ou.unet_forward(P, topo, xc, t_emb=t_emb)
+    elif kind == "encoder":
+        out = ou.encoder_forward(P, topo, xc, t)
+    else:
+        out = ou.unet_forward(P, topo, xc, timesteps=t)
+    assert rel_l2(out, g["out"]) < TOL
+
+
+# ----------------------------------------------------------------------------- samplers
+
+
+def tiny_nets():
+    Pu = params(ou.TINY_UNET_CFG, "unet", 21)
+    Pe = params(ou.TINY_ENC_CFG, "encoder", 22)
+    Pz = synth.synth_state_dict(ou.zemb_manifest(6, 32), synth.SEED_ZEMB)
+    tu = ou.build_topology(ou.TINY_UNET_CFG, "unet")
+    te = ou.build_topology(ou.TINY_ENC_CFG, "encoder")
+    return Pu, Pe, Pz, tu, te
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_drmnet_loop(tag):
+    g = gold(f"drmnet_loop_{tag}")
+    Pu, Pe, Pz, tu, te = tiny_nets()
+    Pe = dict(Pe)
+    Pe["out.3.weight"] = Pe["out.3.weight"] * float(g["head_w_scale"])
+    Pe["out.3.bias"] = torch.from_numpy(g["head_bias"])
+    refnet = lambda xc, t: ou.encoder_forward(Pe, te, xc, t)
+    illnet = lambda xc, dz: ou.unet_forward(Pu, tu, xc, t_emb=ou.z_embed(Pz, dz))
+    trace = []
+    Lr0, zK, K = osamp.drmnet_sample(
+        refnet, illnet, torch.from_numpy(g["LrK"]), torch.from_numpy(g["noise0"]), torch.from_numpy(g["step_noise"]),
+        torch.from_numpy(g["z0"]), float(g["gamma"]), float(g["epsilon"]), float(g["delta"]), int(g["max_timesteps"]), trace=trace,
+    )
+    assert K.tolist() == g["K"].tolist()
+    assert np.array_equal(np.isnan(zK.numpy()), np.isnan(g["zK"]))
+    assert np.allclose(np.nan_to_num(zK.numpy()), np.nan_to_num(g["zK"]), atol=1e-5)
+    assert rel_l2(Lr0, g["Lr0"]) < 1e-4  # chain of <=17 steps
+
+
+@pytest.mark.parametrize("eta", [0, 1])
+def test_ddim_trace(eta):
+    g = gold(f"ddim_trace_eta{eta}")
+    Pu, _, _, tu, _ = tiny_nets()
+    S = osamp.ddpm_schedule(1000, 1e-4, 0.09)
+    d = osamp.ddim_schedule(S["alphas_cumprod"], 1000, 50, float(eta))
+    eps_model = lambda xc, t: ou.unet_forward(Pu, tu, xc, timesteps=t)
+    x, xs = osamp.ddim_sample(eps_model, torch.from_numpy(g["cond"]), torch.from_numpy(g["x_T"]), torch.from_numpy(g["noise"]), d)
+    assert rel_l2(xs[0], g["x_inter"][0]) < TOL
+    assert rel_l2(x, g["x"]) < 2e-4  # 50-step chain
+
+
+def test_ddpm_trace():
+    g = gold("ddpm_trace")
+    Pu, _, _, tu, _ = tiny_nets()
+    S = osamp.ddpm_schedule(1000, 1e-4, 0.09)
+    eps_model = lambda xc, t: ou.unet_forward(Pu, tu, xc, timesteps=t)
+    pred_x0, img, imgs = osamp.ddpm_sample(eps_model, torch.from_numpy(g["cond"]), torch.from_numpy(g["x_T"]), torch.from_numpy(g["noise"]), S, start_T=6)
+    assert rel_l2(imgs[0], g["x_inter"][0]) < TOL
+    assert rel_l2(img, g["x_inter"][-1]) < 1e-4
+    assert rel_l2(pred_x0, g["pred_x0"]) < 1e-4

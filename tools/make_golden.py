@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE's own Python on CPU in this container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [--only NAME ...]
+
+Needs /root/reference (read-only).  Writes only data (npz/json) -- no reference
+source, bytecode or text is stored.  Weights are the seeded rule of
+drmnet_amd/synth.py, loaded into the reference modules by state_dict order; the
+fixtures keep (seed, checksums), not the weights.  All noise is injected by
+patching the reference's RNG call sites (torch.randn_like in models/drmnet.py:797,823;
+noise_like in ddim.py:256 / ddpm.py:1156) so traces are reproducible.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import refharness as rh  # noqa: E402
+from drmnet_amd import synth  # noqa: E402
+from oracle import unet as ou  # only for the CFG dicts (restated from the YAMLs)  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def gen(seed):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return g
+
+
+def load_rule(module, seed):
+    synth.load_synth(module, seed)
+    return synth.checksum(torch.cat([v.flatten() for v in module.state_dict().values()]))
+
+
+# ----------------------------------------------------------------------------- manifests
+
+
+def make_manifests(oa):
+    out = {}
+    for name, cfg, cls in (
+        ("illnet", ou.ILLNET_CFG, oa.UNetModel),
+        ("refnet", ou.REFNET_CFG, oa.EncoderUNetModel),
+        ("obsnet", ou.OBSNET_CFG, oa.UNetModel),
+        ("tiny_unet", ou.TINY_UNET_CFG, oa.UNetModel),
+        ("tiny_enc", ou.TINY_ENC_CFG, oa.EncoderUNetModel),
+    ):
+        m = cls(**cfg)
+        out[name] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        print(f"  {name}: {len(out[name])} tensors, {sum(v.numel() for v in m.state_dict().values()) / 1e6:.2f} M params")
+    DRM, OBS, _, _ = rh.ref_classes()
+    cfg = rh.load_yaml_params("configs/drmnet/eval_drmnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    out["drmnet_model"] = [[k, list(v.shape)] for k, v in DRM(**cfg).state_dict().items()]
+    cfg = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    out["obsnet_model"] = [[k, list(v.shape)] for k, v in OBS(**cfg).state_dict().items()]
+    with open(os.path.join(GOLD, "manifests.json"), "w") as f:
+        json.dump(out, f)
+    print("  wrote manifests.json")
+
+
+# ----------------------------------------------------------------------------- primitives / schedules
+
+
+def make_primitives(oa):
+    from ldm.modules.diffusionmodules.util import timestep_embedding
+
+    t = torch.tensor([0, 1, 21, 149, 981, 999], dtype=torch.long)
+    save("timestep_embedding", t=t, emb=timestep_embedding(t, 128))
+
+    DRM, OBS, DDIM, _ = rh.ref_classes()
+    cfg = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    cfg["unet_config"] = {"target": cfg["unet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    m = OBS(**cfg).eval()
+    names = [
+        "betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+        "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+        "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2",
+    ]
+    save("ddpm_schedule", **{n: getattr(m, n) for n in names})
+    for eta in (0.0, 1.0):
+        s = DDIM(m)
+        s.make_schedule(ddim_num_steps=50, ddim_eta=eta, verbose=False)
+        # the five fp32 scalars p_sample_ddim derives per index (ddim.py:243-258)
+        coef = np.zeros((50, 5), dtype=np.float32)
+        for i in range(50):
+            a_t = torch.full((1,), s.ddim_alphas[i])
+            a_prev = torch.full((1,), s.ddim_alphas_prev[i])
+            sigma = torch.full((1,), s.ddim_sigmas[i])
+            s1m = torch.full((1,), s.ddim_sqrt_one_minus_alphas[i])
+            coef[i] = [a_t.sqrt().item(), s1m.item(), a_prev.sqrt().item(), (1.0 - a_prev - sigma**2).sqrt().item(), sigma.item()]
+        save(f"ddim_schedule_eta{int(eta)}", timesteps=s.ddim_timesteps, coef=coef,
+             alphas=np.asarray(s.ddim_alphas, dtype=np.float64), alphas_prev=np.asarray(s.ddim_alphas_prev, dtype=np.float64),
+             sigmas=np.asarray(s.ddim_sigmas, dtype=np.float64))
+
+
+def make_brdf_schedule():
+    DRM, _, _, _ = rh.ref_classes()
+    cfg = rh.load_yaml_params("configs/drmnet/eval_drmnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    cfg["illnet_config"] = {"target": cfg["illnet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    cfg["refnet_config"] = {"target": cfg["refnet_config"]["target"], "params": dict(ou.TINY_ENC_CFG)}
+    m = DRM(**cfg).eval()
+    g = gen(77)
+    z_out = torch.rand((16, 6), generator=g) * 1.6 - 0.3
+    z_out[0] = m.z0  # exactly converged row (distance == 0 branch)
+    z_out[1] = m.z0 + 1e-3
+    arrs = {"z_out": z_out, "z0": m.z0, "gamma": m.gamma, "epsilon": m.epsilon}
+    for i in (0, 1, 7, 50, 90, 149):
+        zk, zK = m.get_brdf_out(z_out, reversed_k=i)
+        arrs[f"zk_{i}"] = zk
+        arrs[f"conv_{i}"] = m.check_convergence(zk)
+        arrs["zK"] = zK
+    save("brdf_schedule", **arrs)
+
+
+# ----------------------------------------------------------------------------- U-Net forwards
+
+
+def make_tiny_nets(oa):
+    g = gen(11)
+    for tag, (h, w) in (("16x16", (16, 16)), ("16x32", (16, 32))):
+        x = torch.randn((2, 6, h, w), generator=g)
+        t = torch.tensor([3, 977], dtype=torch.long)
+        t_emb = torch.randn((2, 32), generator=g)
+        u = oa.UNetModel(**ou.TINY_UNET_CFG).eval()
+        cs = load_rule(u, 21)
+        with torch.no_grad():
+            save(f"tiny_unet_{tag}", x=x, t=t, t_emb=t_emb, out_t=u(x, timesteps=t), out_temb=u(x, t_emb=t_emb), seed=21, wsum=cs)
+        e = oa.EncoderUNetModel(**ou.TINY_ENC_CFG).eval()
+        cs = load_rule(e, 22)
+        with torch.no_grad():
+            save(f"tiny_enc_{tag}", x=x, t=t, out=e(x, t), seed=22, wsum=cs)
+
+
+def block_inputs(kind, a, b, h, w, n):
+    """Regenerable inputs for the single-block fixtures (tests rebuild them from the same seed)."""
+    g = gen(1000 + a + 7 * b + 13 * h + 17 * w)
+    emb = torch.randn((n, 512), generator=g)
+    x = torch.randn((n, a, h, w), generator=g)
+    return x, emb
+
+
+def make_blocks(oa):
+    """Full-width single blocks from the reference classes (weights by rule; inputs regenerable; only outputs stored)."""
+    for cin, cout, hw, n in ((256, 128, 16, 2), (128, 128, 16, 2), (1536, 768, 4, 2)):
+        rb = oa.ResBlock(cin, 512, 0.0, out_channels=cout).eval()
+        cs = load_rule(rb, 31)
+        x, emb = block_inputs("res", cin, cout, hw, hw, n)
+        with torch.no_grad():
+            save(f"resblock_{cin}_{cout}_{hw}", out=rb(x, emb), seed=31, wsum=cs, xsum=synth.checksum(x), n=n)
+    for ch, h, w, n in ((512, 16, 16, 2), (384, 32, 32, 1), (768, 4, 8, 2)):
+        ab = oa.AttentionBlock(ch, num_heads=1, num_head_channels=-1).eval()
+        cs = load_rule(ab, 32)
+        x, _ = block_inputs("attn", ch, ch, h, w, n)
+        with torch.no_grad():
+            save(f"attnblock_{ch}_{h}x{w}", out=ab(x), seed=32, wsum=cs, xsum=synth.checksum(x), n=n)
+
+
+def full_inputs(n, h, w):
+    x = synth.synth_refmaps(n, h, w, synth.SEED_INPUT)
+    g = gen(synth.SEED_INPUT + 1)
+    xk = x + 0.025 * torch.randn(x.shape, generator=g)
+    t_emb = torch.randn((n, 128), generator=g)
+    return torch.cat([xk, x], dim=1).contiguous(), t_emb
+
+
+def make_full_nets(oa):
+    for name, cfg, cls, seed in (
+        ("illnet", ou.ILLNET_CFG, oa.UNetModel, synth.SEED_ILLNET),
+        ("refnet", ou.REFNET_CFG, oa.EncoderUNetModel, synth.SEED_REFNET),
+        ("obsnet", ou.OBSNET_CFG, oa.UNetModel, synth.SEED_OBSNET),
+    ):
+        m = cls(**cfg).eval()
+        cs = load_rule(m, seed)
+        for n, h, w in ((2, 128, 128), (1, 128, 256)):
+            xc, t_emb = full_inputs(n, h, w)
+            t = torch.tensor([7, 981][:n], dtype=torch.long)
+            t0 = time.time()
+            with torch.no_grad():
+                if name == "illnet":
+                    out = m(xc, t_emb=t_emb)
+                else:
+                    out = m(xc, t)
+            print(f"  {name} {n}x{h}x{w}: {time.time() - t0:.1f}s  out std {out.std():.4f} absmax {out.abs().max():.3f}")
+            save(f"full_{name}_{h}x{w}", out=out, t=t, seed=seed, wsum=cs, xsum=synth.checksum(xc), tembsum=synth.checksum(t_emb))
+
+
+# ----------------------------------------------------------------------------- samplers
+
+
+def tiny_drmnet(gamma, epsilon, max_timesteps, delta=0.025):
+    DRM, _, _, _ = rh.ref_classes()
+    cfg = rh.load_yaml_params("configs/drmnet/eval_drmnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    cfg["illnet_config"] = {"target": cfg["illnet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    cfg["refnet_config"] = {"target": cfg["refnet_config"]["target"], "params": dict(ou.TINY_ENC_CFG)}
+    cfg.update(image_size=16, gamma=gamma, epsilon=epsilon, max_timesteps=max_timesteps, delta=delta, use_ema=False)
+    m = DRM(**cfg).eval()
+    synth.load_synth(m.illnet_model.diffusion_model, 21)
+    synth.load_synth(m.refnet_model.diffusion_model, 22)
+    zsd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in m.illnet_model.z_emb_layer.state_dict().items()], synth.SEED_ZEMB)
+    m.illnet_model.z_emb_layer.load_state_dict(zsd)
+    return m
+
+
+def make_drmnet_loop():
+    import models.drmnet as refdrm
+
+    for tag, (h, w), gamma, eps, T, wscale in (("a", (16, 16), 0.9, 0.78, 17, 10.0), ("b", (16, 32), 0.92, 0.715, 15, 6.0)):
+        m = tiny_drmnet(gamma=gamma, epsilon=eps, max_timesteps=T)
+        # spread the per-sample convergence step: amplify the RefNet head and centre it near z0
+        head = m.refnet_model.diffusion_model.out[3]
+        head_bias = torch.tensor([0.95, 0.9, 0.97, 0.92, 0.05, 0.9])
+        with torch.no_grad():
+            head.weight.mul_(wscale)
+            head.bias.copy_(head_bias)
+        B = 5
+        g = gen(41)
+        LrK = synth.synth_refmaps(B, h, w, 99)
+        noise0 = torch.randn(LrK.shape, generator=g)
+        step_noise = torch.randn((T,) + tuple(LrK.shape), generator=g)
+        # make one row converge immediately: bias RefNet head so z_out ~ z0 is impossible per-row; instead rely on spread.
+        state = {"call": 0, "active": torch.ones(B, dtype=torch.bool), "nc_idx": None, "step": 0}
+        orig_randn_like = torch.randn_like
+        orig_check = m.check_convergence
+
+        def check(zk):
+            conv = orig_check(zk)
+            idx = torch.where(state["active"])[0]
+            state["nc_idx"] = idx[~conv]
+            state["active"][idx[conv]] = False
+            return conv
+
+        def randn_like(t, **kw):
+            if state["call"] == 0:
+                state["call"] += 1
+                return noise0.clone()
+            out = step_noise[state["step"]][state["nc_idx"]]
+            assert out.shape == t.shape, (out.shape, t.shape)
+            state["step"] += 1
+            state["call"] += 1
+            return out
+
+        m.check_convergence = check
+        refdrm.torch.randn_like = randn_like
+        try:
+            Lr0, zK, K, inter = m.p_sample_loop(LrK, [LrK], [LrK], return_intermediates=True, verbose=False, log_every_k=1)
+        finally:
+            refdrm.torch.randn_like = orig_randn_like
+        print(f"  drmnet loop {tag}: K = {K.tolist()}  zK nan rows = {torch.isnan(zK).any(dim=1).tolist()}")
+        save(f"drmnet_loop_{tag}", LrK=LrK, noise0=noise0, step_noise=step_noise, Lr0=Lr0, zK=zK, K=K, z0=m.z0,
+             gamma=gamma, epsilon=eps, delta=0.025, max_timesteps=T, head_w_scale=wscale, head_bias=head_bias,
+             Lrk_steps=torch.stack(inter["Lrk_inter"][1:]), zk_steps=torch.stack(inter["zk_inter"]))
+
+
+def tiny_obsnet():
+    _, OBS, DDIM, _ = rh.ref_classes()
+    cfg = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    cfg["unet_config"] = {"target": cfg["unet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    cfg.update(image_size=16, use_ema=False)
+    m = OBS(**cfg).eval()
+    synth.load_synth(m.model.diffusion_model, 21)
+    return m, DDIM
+
+
+def make_obsnet_samplers():
+    import ldm.models.diffusion.ddim as refddim
+    import ldm.models.diffusion.ddpm as refddpm
+
+    m, DDIM = tiny_obsnet()
+    B, h, w = 3, 16, 16
+    g = gen(51)
+    cond = synth.synth_refmaps(B, h, w, 98) * 2 - 1
+    x_T = torch.randn((B, 3, h, w), generator=g)
+    noise = torch.randn((50, B, 3, h, w), generator=g)
+    ctr = {"i": 0}
+
+    def noise_like(shape, device, repeat=False):
+        out = noise[ctr["i"]]
+        ctr["i"] += 1
+        assert tuple(out.shape) == tuple(shape)
+        return out
+
+    o1, o2 = refddim.noise_like, refddpm.noise_like
+    refddim.noise_like = noise_like
+    refddpm.noise_like = noise_like
+    try:
+        for eta in (1.0, 0.0):
+            ctr["i"] = 0
+            x, inter = DDIM(m).sample(50, B, (3, h, w), cond, eta=eta, x_T=x_T, verbose=False, log_every_t=1)
+            save(f"ddim_trace_eta{int(eta)}", cond=cond, x_T=x_T, noise=noise, x=x, x_inter=torch.stack(inter["x_inter"][1:]))
+        ctr["i"] = 0
+        pred_x0, inter = m.p_sample_loop(cond, (B, 3, h, w), return_intermediates=True, x_T=x_T, verbose=False, start_T=6, log_every_t=1)
+        save("ddpm_trace", cond=cond, x_T=x_T, noise=noise[:6], pred_x0=pred_x0, x_inter=torch.stack(inter["x_inter"][1:]))
+    finally:
+        refddim.noise_like, refddpm.noise_like = o1, o2
+
+
+STEPS = {
+    "manifests": lambda oa: make_manifests(oa),
+    "primitives": lambda oa: make_primitives(oa),
+    "brdf": lambda oa: make_brdf_schedule(),
+    "tiny": lambda oa: make_tiny_nets(oa),
+    "blocks": lambda oa: make_blocks(oa),
+    "drmnet_loop": lambda oa: make_drmnet_loop(),
+    "obsnet_samplers": lambda oa: make_obsnet_samplers(),
+    "full": lambda oa: make_full_nets(oa),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    _, _, _, oa = rh.ref_classes()
+    for name, fn in STEPS.items():
+        if args.only and name not in args.only:
+            continue
+        print(f"[{name}]")
+        fn(oa)
+    meta = {"torch": torch.__version__, "numpy": np.__version__, "reference": "kyotovision-public/DRMNet @ /root/reference (2025-02-23)"}
+    with open(os.path.join(GOLD, "META.json"), "w") as f:
+        json.dump(meta, f)
+
+
+if __name__ == "__main__":
+    main()
