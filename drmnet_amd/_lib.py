@@ -1,0 +1,134 @@
+"""ctypes binding of include/drmnet_hip.h (libdrmnet_hip.so).
+
+The product path has NO fallback: if the library is missing or a call fails, a
+RuntimeError is raised (the reference's only error style is Python exceptions /
+asserts, e.g. openaimodel.py:740-749).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdrmnet_hip.so")
+MAX_LEVELS = 8
+
+# every symbol include/drmnet_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "drm_abi_version", "drm_last_error",
+    "drm_unet_create", "drm_unet_destroy", "drm_unet_param_count", "drm_unet_param_info", "drm_unet_load_params",
+    "drm_unet_workspace_bytes", "drm_unet_forward",
+    "drm_linear_forward", "drm_timestep_embedding", "drm_op_norm_act_conv", "drm_op_resblock", "drm_op_attention_block",
+    "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_step", "drm_drmnet_sample",
+    "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddpm_sample", "drm_randn",
+]
+
+
+class UNetDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("in_channels", C.c_int32), ("model_channels", C.c_int32), ("out_channels", C.c_int32),
+        ("num_res_blocks", C.c_int32), ("n_levels", C.c_int32), ("channel_mult", C.c_int32 * MAX_LEVELS),
+        ("n_attn", C.c_int32), ("attention_resolutions", C.c_int32 * MAX_LEVELS),
+    ]
+
+
+class DrmnetCfg(C.Structure):
+    _fields_ = [
+        ("z_dim", C.c_int32), ("max_timesteps", C.c_int32), ("gamma", C.c_double), ("epsilon", C.c_float), ("delta", C.c_float),
+        ("z0", C.c_float * 8),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m drmnet_amd.build` (hipcc, gfx950). "
+            "drmnet_amd has no CPU / PyTorch fallback for the hot path."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64p, fp = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p
+    L.drm_abi_version.restype = C.c_int
+    L.drm_last_error.restype = C.c_char_p
+    L.drm_unet_create.argtypes = [C.POINTER(UNetDesc), C.POINTER(vp)]
+    L.drm_unet_destroy.argtypes = [vp]
+    L.drm_unet_destroy.restype = None
+    L.drm_unet_param_count.argtypes = [vp]
+    L.drm_unet_param_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    L.drm_unet_load_params.argtypes = [vp, C.POINTER(vp), i32, vp]
+    L.drm_unet_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    L.drm_unet_workspace_bytes.restype = C.c_size_t
+    L.drm_unet_forward.argtypes = [vp, fp, i32, fp, i32, vp, fp, i64p, fp, fp, i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_linear_forward.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp]
+    L.drm_timestep_embedding.argtypes = [i64p, fp, i32, i32, vp]
+    L.drm_op_norm_act_conv.argtypes = [fp, fp, fp, i32, fp, fp, i32, fp, fp, fp, i32, i32, i32, i32, i32, vp]
+    L.drm_op_resblock.argtypes = [fp, i32, i32, fp, i32, fp, i32, C.POINTER(vp), i32, fp, i32, i32, i32, i32, vp]
+    L.drm_op_attention_block.argtypes = [fp, C.POINTER(vp), fp, i32, i32, i32, i32, vp]
+    L.drm_drmnet_create.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(DrmnetCfg), C.POINTER(vp)]
+    L.drm_drmnet_destroy.argtypes = [vp]
+    L.drm_drmnet_destroy.restype = None
+    L.drm_drmnet_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    L.drm_drmnet_workspace_bytes.restype = C.c_size_t
+    L.drm_drmnet_step.argtypes = [vp, fp, fp, vp, i32, i32, fp, C.c_uint64, fp, fp, vp, i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_drmnet_sample.argtypes = [vp, fp, fp, fp, C.c_uint64, i32, fp, fp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_sampler_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    L.drm_sampler_workspace_bytes.restype = C.c_size_t
+    L.drm_ddim_sample.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_ddpm_sample.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_randn.argtypes = [fp, C.c_size_t, C.c_uint64, C.c_uint64, vp]
+    if L.drm_abi_version() != 1:
+        raise RuntimeError("libdrmnet_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = lib().drm_last_error()
+        raise RuntimeError(f"drmnet_hip error {status}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (drmnet_amd has no CPU path); got device {t.device}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class Workspace:
+    """Caller-owned scratch, grown on demand and reused (torch allocator owns the memory)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if nbytes == 0:
+            raise RuntimeError(f"workspace query failed: {lib().drm_last_error().decode()}")
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = None
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf

@@ -1,0 +1,366 @@
+// extern "C" surface of libdrmnet_hip.so (declared in include/drmnet_hip.h).
+#include <cstring>
+#include <memory>
+
+#include "samplers.h"
+
+using namespace drm;
+
+struct drm_unet {
+  UNet net;
+};
+struct drm_drmnet {
+  DrmnetSampler s;
+};
+
+namespace {
+
+// RAII device scratch for the op-level entry points (tests / per-module drop-ins only).
+struct Scratch {
+  void* p = nullptr;
+  hipStream_t s;
+  explicit Scratch(hipStream_t st) : s(st) {}
+  int reserve(size_t bytes) { DRM_HIP_CHECK(hipMalloc(&p, bytes)); return DRM_OK; }
+  ~Scratch() {
+    if (p) {
+      (void)hipStreamSynchronize(s);
+      (void)hipFree(p);
+    }
+  }
+};
+
+int make_arena(Arena& ar, void* ws, size_t bytes, size_t need) {
+  if (need == 0) return DRM_ERR_INVALID;  // error text already set by the dry run
+  if (bytes < need || ws == nullptr) {
+    set_error("workspace too small: need " + std::to_string(need) + " bytes, got " + std::to_string(bytes));
+    return DRM_ERR_WORKSPACE;
+  }
+  ar.base = static_cast<char*>(ws);
+  ar.cap = bytes;
+  return DRM_OK;
+}
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::exception& e) {
+    set_error(std::string("exception: ") + e.what());
+    return DRM_ERR_STATE;
+  } catch (...) {
+    set_error("unknown exception");
+    return DRM_ERR_STATE;
+  }
+}
+
+// shared driver for the two block-level ops: runs `body` twice (measure, then execute) over a private scratch arena
+template <typename Body>
+int with_scratch(hipStream_t s, Body&& body) {
+  Arena dry;
+  dry.dry = true;
+  DRM_TRY(body(dry));
+  Scratch sc(s);
+  DRM_TRY(sc.reserve(dry.peak + 256));
+  Arena ar;
+  ar.base = static_cast<char*>(sc.p);
+  ar.cap = dry.peak + 256;
+  DRM_HIP_CHECK(hipMemsetAsync(sc.p, 0, ar.cap, s));
+  DRM_TRY(body(ar));
+  DRM_HIP_CHECK(hipStreamSynchronize(s));
+  return DRM_OK;
+}
+
+size_t unet_ws(UNet& net, int N, int H, int W) {
+  Arena a;
+  a.dry = true;
+  const int Cx = net.desc.kind == 0 ? net.desc.out_channels : net.desc.in_channels / 2;
+  if (net.forward(nullptr, Cx, nullptr, net.desc.in_channels - Cx, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a, nullptr) != DRM_OK) return 0;
+  return a.peak + 256;
+}
+
+}  // namespace
+
+extern "C" {
+
+int drm_abi_version(void) { return DRM_ABI_VERSION; }
+const char* drm_last_error(void) { return last_error(); }
+
+int drm_unet_create(const drm_unet_desc* desc, drm_unet** out) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(desc && out, "null argument");
+    std::unique_ptr<drm_unet> h(new drm_unet());
+    DRM_TRY(h->net.build(*desc));
+    *out = h.release();
+    return DRM_OK;
+  });
+}
+void drm_unet_destroy(drm_unet* net) { delete net; }
+
+int drm_unet_param_count(const drm_unet* net) { return net ? (int)net->net.params.size() : -1; }
+
+int drm_unet_param_info(const drm_unet* net, int index, char* name, int name_cap, int64_t shape[4], int* ndim) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && index >= 0 && index < (int)net->net.params.size(), "param index");
+    const ParamSlot& p = net->net.params[index];
+    if (name && name_cap > 0) {
+      std::strncpy(name, p.name.c_str(), name_cap - 1);
+      name[name_cap - 1] = 0;
+    }
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape)
+      for (size_t i = 0; i < 4; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return DRM_OK;
+  });
+}
+
+int drm_unet_load_params(drm_unet* net, const float* const* ptrs, int count, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && ptrs, "null argument");
+    return net->net.load(ptrs, count, static_cast<hipStream_t>(stream));
+  });
+}
+
+size_t drm_unet_workspace_bytes(const drm_unet* net, int N, int H, int W) {
+  if (!net) return 0;
+  size_t r = 0;
+  guarded([&]() -> int {
+    r = unet_ws(const_cast<drm_unet*>(net)->net, N, H, W);
+    return DRM_OK;
+  });
+  return r;
+}
+
+int drm_unet_forward(drm_unet* net, const float* x, int Cx, const float* cond, int Cc, const int32_t* rows, const float* t_emb,
+                     const int64_t* timesteps, const float* timesteps_f, float* out, int N, int H, int W, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && x && out, "null argument");
+    DRM_REQUIRE(Cc == 0 || cond, "cond is null but Cc > 0");
+    Arena ar;
+    DRM_TRY(make_arena(ar, workspace, workspace_bytes, unet_ws(net->net, N, H, W)));
+    return net->net.forward(x, Cx, cond, Cc, rows, t_emb, timesteps, timesteps_f, out, N, H, W, ar, static_cast<hipStream_t>(stream));
+  });
+}
+
+// ------------------------------------------------------------------------------------------------ primitive ops
+
+int drm_linear_forward(const float* in, const float* w, const float* b, float* out, int N, int I, int O, int silu_in, int silu_out, void* stream) {
+  return guarded([&]() -> int { return launch_linear(in, w, b, out, N, I, O, silu_in, silu_out, static_cast<hipStream_t>(stream)); });
+}
+
+int drm_timestep_embedding(const int64_t* timesteps, float* out, int N, int dim, void* stream) {
+  return guarded([&]() -> int { return launch_timestep_embedding(timesteps, nullptr, out, N, dim, static_cast<hipStream_t>(stream)); });
+}
+
+int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, int silu, const float* w, const float* b, int ksize,
+                         const float* emb, const float* residual, float* out, int N, int Cin, int Cout, int H, int W, void* stream) {
+  return guarded([&]() -> int {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DRM_REQUIRE(ksize == 1 || ksize == 3, "ksize");
+    DRM_REQUIRE((gamma == nullptr) == (beta == nullptr), "gamma/beta");
+    DRM_REQUIRE(!gamma || Cin % 32 == 0, "GroupNorm32 needs Cin % 32 == 0");
+    const int taps = ksize * ksize;
+    const int cinp = (ksize == 1) ? (Cin + 31) / 32 * 32 : (Cin + 7) / 8 * 8, coutp = (Cout + 31) / 32 * 32;
+    DRM_REQUIRE((!residual && !emb) || Cout == coutp, "residual/emb need Cout % 32 == 0");
+    const size_t hw = (size_t)H * W;
+    return with_scratch(s, [&](Arena& ar) -> int {
+      Ctx c{&ar, s, N};
+      Act xa = new_act(c, cinp, H, W);
+      float* wp = ar.alloc<float>(packed_conv_weight_floats(taps, coutp, cinp));
+      float* bp = ar.alloc<float>(coutp);
+      float* sc = ar.alloc<float>((size_t)N * cinp);
+      float* sh = ar.alloc<float>((size_t)N * cinp);
+      float* resn = ar.alloc<float>(N * hw * coutp);
+      float* gp = ar.alloc<float>(cinp);
+      float* bpn = ar.alloc<float>(cinp);
+      if (ar.dry) {
+        xa.mom_valid = false;
+        return ensure_moments(c, xa);
+      }
+      DRM_TRY(launch_pack_input(x, nullptr, nullptr, xa.p, N, H, W, Cin, 0, cinp, s));
+      DRM_TRY(launch_pack_conv_weight(w, wp, Cout, Cin, taps, coutp, cinp, s));
+      if (b) DRM_HIP_CHECK(hipMemcpyAsync(bp, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+      ConvArgs a;
+      if (gamma) {
+        DRM_HIP_CHECK(hipMemcpyAsync(gp, gamma, Cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+        DRM_HIP_CHECK(hipMemcpyAsync(bpn, beta, Cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+        DRM_TRY(ensure_moments(c, xa));
+        DRM_TRY(launch_gn_finalize(xa.mom, cinp, nullptr, 0, gp, bpn, N, sc, sh, s));
+        a.gn_scale = sc; a.gn_shift = sh;
+      }
+      if (residual) {
+        DRM_TRY(launch_nchw_to_nhwc(residual, resn, N, H, W, Cout, s));
+        a.res = resn;
+      }
+      a.src0 = xa.p; a.C0 = cinp; a.N = N; a.H = H; a.W = W; a.silu = silu;
+      a.w = wp; a.bias = bp; a.taps = taps; a.Cout = coutp;
+      a.emb = emb; a.emb_stride = Cout;
+      a.out = out; a.out_nchw = 1; a.cout_valid = Cout;
+      return launch_conv(a, s);
+    });
+  });
+}
+
+int drm_op_resblock(const float* x0, int C0, int up0, const float* x1, int C1, const float* emb, int emb_dim, const float* const* params,
+                    int n_params, float* out, int N, int Cout, int H, int W, void* stream) {
+  return guarded([&]() -> int {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int cin = C0 + C1;
+    const bool has_skip = cin != Cout;
+    DRM_REQUIRE(n_params == (has_skip ? 12 : 10), "resblock expects 10 params (12 with skip_connection)");
+    DRM_REQUIRE(cin % 32 == 0 && Cout % 32 == 0 && C0 % 32 == 0, "channels % 32");
+    DRM_REQUIRE(emb_dim <= 512, "emb_dim <= 512");
+    return with_scratch(s, [&](Arena& ar) -> int {
+      Ctx c{&ar, s, N};
+      // packed weights laid out like UNet::add_res
+      ResLayer r;
+      r.cin = cin; r.cout = Cout; r.has_skip = has_skip; r.emb_off = 0;
+      float* wb = ar.alloc<float>(1);  // base pointer for offsets
+      auto off = [&](float* p) { return (size_t)(p - wb); };
+      float* n1w = ar.alloc<float>(cin); float* n1b = ar.alloc<float>(cin);
+      float* c1w = ar.alloc<float>(packed_conv_weight_floats(9, Cout, cin)); float* c1b = ar.alloc<float>(Cout);
+      float* n2w = ar.alloc<float>(Cout); float* n2b = ar.alloc<float>(Cout);
+      float* c2w = ar.alloc<float>(packed_conv_weight_floats(9, Cout, Cout)); float* c2b = ar.alloc<float>(Cout);
+      float* skw = ar.alloc<float>(packed_conv_weight_floats(1, Cout, cin)); float* skb = ar.alloc<float>(Cout);
+      float* e_out = ar.alloc<float>((size_t)N * Cout);
+      Act a0 = new_act(c, C0, H, W);
+      a0.up = up0;
+      Act a1 = new_act(c, C1 > 0 ? C1 : 4, H, W);
+      Act o = new_act(c, Cout, H, W);
+      if (!ar.dry) {
+        r.n1_w = off(n1w); r.n1_b = off(n1b); r.c1_w = off(c1w); r.c1_b = off(c1b); r.n2_w = off(n2w); r.n2_b = off(n2b);
+        r.c2_w = off(c2w); r.c2_b = off(c2b); r.sk_w = off(skw); r.sk_b = off(skb);
+        auto cp = [&](float* d, const float* sp, size_t n) -> int {
+          DRM_HIP_CHECK(hipMemcpyAsync(d, sp, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+          return DRM_OK;
+        };
+        DRM_TRY(cp(n1w, params[0], cin)); DRM_TRY(cp(n1b, params[1], cin));
+        DRM_TRY(launch_pack_conv_weight(params[2], c1w, Cout, cin, 9, Cout, cin, s)); DRM_TRY(cp(c1b, params[3], Cout));
+        DRM_TRY(launch_linear(emb, params[4], params[5], e_out, N, emb_dim, Cout, 1, 0, s));
+        DRM_TRY(cp(n2w, params[6], Cout)); DRM_TRY(cp(n2b, params[7], Cout));
+        DRM_TRY(launch_pack_conv_weight(params[8], c2w, Cout, Cout, 9, Cout, Cout, s)); DRM_TRY(cp(c2b, params[9], Cout));
+        if (has_skip) {
+          DRM_TRY(launch_pack_conv_weight(params[10], skw, Cout, cin, 1, Cout, cin, s)); DRM_TRY(cp(skb, params[11], Cout));
+        }
+        DRM_TRY(launch_nchw_to_nhwc(x0, a0.p, N, H >> up0, W >> up0, C0, s));
+        if (C1 > 0) DRM_TRY(launch_nchw_to_nhwc(x1, a1.p, N, H, W, C1, s));
+      }
+      DRM_TRY(run_resblock(c, wb, r, a0, C1 > 0 ? &a1 : nullptr, e_out, Cout, o));
+      if (!ar.dry) DRM_TRY(launch_nhwc_to_nchw(o.p, out, N, H, W, Cout, s));
+      return DRM_OK;
+    });
+  });
+}
+
+int drm_op_attention_block(const float* x, const float* const* params, float* out, int N, int C, int H, int W, void* stream) {
+  return guarded([&]() -> int {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DRM_REQUIRE(C % 32 == 0, "channels % 32");
+    return with_scratch(s, [&](Arena& ar) -> int {
+      Ctx c{&ar, s, N};
+      AttnLayer l;
+      l.ch = C;
+      float* wb = ar.alloc<float>(1);
+      auto off = [&](float* p) { return (size_t)(p - wb); };
+      float* nw = ar.alloc<float>(C); float* nb = ar.alloc<float>(C);
+      float* qw = ar.alloc<float>(packed_conv_weight_floats(1, 3 * C, C)); float* qb = ar.alloc<float>(3 * C);
+      float* pw = ar.alloc<float>(packed_conv_weight_floats(1, C, C)); float* pb = ar.alloc<float>(C);
+      Act a = new_act(c, C, H, W);
+      Act o = new_act(c, C, H, W);
+      if (!ar.dry) {
+        l.n_w = off(nw); l.n_b = off(nb); l.qkv_w = off(qw); l.qkv_b = off(qb); l.proj_w = off(pw); l.proj_b = off(pb);
+        DRM_HIP_CHECK(hipMemcpyAsync(nw, params[0], C * sizeof(float), hipMemcpyDeviceToDevice, s));
+        DRM_HIP_CHECK(hipMemcpyAsync(nb, params[1], C * sizeof(float), hipMemcpyDeviceToDevice, s));
+        DRM_TRY(launch_pack_conv_weight(params[2], qw, 3 * C, C, 1, 3 * C, C, s));
+        DRM_HIP_CHECK(hipMemcpyAsync(qb, params[3], 3 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+        DRM_TRY(launch_pack_conv_weight(params[4], pw, C, C, 1, C, C, s));
+        DRM_HIP_CHECK(hipMemcpyAsync(pb, params[5], C * sizeof(float), hipMemcpyDeviceToDevice, s));
+        DRM_TRY(launch_nchw_to_nhwc(x, a.p, N, H, W, C, s));
+      }
+      DRM_TRY(run_attention(c, wb, l, a, o));
+      if (!ar.dry) DRM_TRY(launch_nhwc_to_nchw(o.p, out, N, H, W, C, s));
+      return DRM_OK;
+    });
+  });
+}
+
+// ------------------------------------------------------------------------------------------------ samplers
+
+int drm_drmnet_create(drm_unet* illnet, drm_unet* refnet, const float* const* zemb, const drm_drmnet_cfg* cfg, drm_drmnet** out) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(illnet && refnet && zemb && cfg && out, "null argument");
+    std::unique_ptr<drm_drmnet> h(new drm_drmnet());
+    DRM_TRY(h->s.init(&illnet->net, &refnet->net, zemb, *cfg));
+    *out = h.release();
+    return DRM_OK;
+  });
+}
+void drm_drmnet_destroy(drm_drmnet* s) { delete s; }
+
+size_t drm_drmnet_workspace_bytes(const drm_drmnet* s, int N, int H, int W) {
+  if (!s) return 0;
+  size_t r = 0;
+  guarded([&]() -> int {
+    r = s->s.workspace_bytes(N, H, W);
+    return DRM_OK;
+  });
+  return r;
+}
+
+int drm_drmnet_step(drm_drmnet* s, float* Lr_k, const float* LrK, const int32_t* rows, int n_active, int step, const float* noise,
+                    uint64_t seed, float* zk_out, float* zK_out, int32_t* converged_out, int B, int H, int W, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(s && Lr_k && LrK, "null argument");
+    Arena ar;
+    DRM_TRY(make_arena(ar, workspace, workspace_bytes, s->s.workspace_bytes(n_active, H, W)));
+    return s->s.step(Lr_k, LrK, rows, n_active, step, noise, seed, zk_out, zK_out, converged_out, B, H, W, ar, static_cast<hipStream_t>(stream));
+  });
+}
+
+int drm_drmnet_sample(drm_drmnet* s, const float* LrK, const float* noise0, const float* step_noise, uint64_t seed, int early_exit,
+                      float* Lr0, float* zK, int32_t* K, int32_t* steps_done, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(s && LrK && Lr0 && zK && K, "null argument");
+    Arena ar;
+    DRM_TRY(make_arena(ar, workspace, workspace_bytes, s->s.workspace_bytes(B, H, W)));
+    return s->s.sample(LrK, noise0, step_noise, seed, early_exit, Lr0, zK, K, steps_done, B, H, W, ar, static_cast<hipStream_t>(stream));
+  });
+}
+
+size_t drm_sampler_workspace_bytes(const drm_unet* net, int N, int H, int W) {
+  if (!net) return 0;
+  size_t r = 0;
+  guarded([&]() -> int {
+    r = sampler_workspace_bytes(&const_cast<drm_unet*>(net)->net, N, H, W);
+    return DRM_OK;
+  });
+  return r;
+}
+
+int drm_ddim_sample(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
+                    const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && x && cond, "null argument");
+    Arena ar;
+    DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
+    return ddim_sample(&net->net, x, cond, timesteps, coef, S, num_steps, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream));
+  });
+}
+
+int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
+                    const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && x && cond, "null argument");
+    Arena ar;
+    DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
+    return ddpm_sample(&net->net, x, pred_x0, cond, coef, T_start, clip_denoised, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream));
+  });
+}
+
+int drm_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+  return guarded([&]() -> int { return launch_randn(out, n, seed, offset, static_cast<hipStream_t>(stream)); });
+}
+
+}  // extern "C"

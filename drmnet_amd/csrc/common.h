@@ -1,0 +1,94 @@
+// Shared declarations for the DRMNet MI355X (gfx950) hot-path library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace drm {
+
+// Thread-local last error text, surfaced through drm_last_error() (C ABI never throws).
+void set_error(const std::string& msg);
+const char* last_error();
+
+#define DRM_OK 0
+#define DRM_ERR_INVALID 1
+#define DRM_ERR_HIP 2
+#define DRM_ERR_WORKSPACE 3
+#define DRM_ERR_STATE 4
+
+#define DRM_HIP_CHECK(expr)                                                                              \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) {                                                                              \
+      ::drm::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                       std::to_string(__LINE__));                                                        \
+      return DRM_ERR_HIP;                                                                                \
+    }                                                                                                    \
+  } while (0)
+
+#define DRM_REQUIRE(cond, msg)                                    \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      ::drm::set_error(std::string("invalid argument: ") + (msg)); \
+      return DRM_ERR_INVALID;                                     \
+    }                                                             \
+  } while (0)
+
+#define DRM_TRY(expr)          \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != DRM_OK) return _s; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Activation layout: NHWC fp32 ("pixels x channels", channels contiguous) everywhere inside the
+// network; NCHW only at the boundary (reference tensors are NCHW).
+// ---------------------------------------------------------------------------------------------
+
+// Fused conv / GEMM descriptor (see conv.hip).
+struct ConvArgs {
+  const float* src0 = nullptr;  // NHWC, C0 channels; if up0, stored at (H/2, W/2) and read nearest-upsampled
+  const float* src1 = nullptr;  // NHWC, C1 channels at (H, W) (skip tensor of the U-Net concat), may be null
+  int C0 = 0, C1 = 0, up0 = 0;
+  int N = 0, H = 0, W = 0;       // conv input == output spatial size (stride 1, pad = taps/2)
+  const float* gn_scale = nullptr;  // [N][C0+C1] per-(sample,channel) GroupNorm scale (rstd*gamma) or null
+  const float* gn_shift = nullptr;  // [N][C0+C1] (beta - mean*rstd*gamma)
+  int silu = 0;                     // apply x*sigmoid(x) after the affine
+  const float* w = nullptr;         // packed [taps][Cin/4][Cout][4]
+  const float* bias = nullptr;      // [Cout]
+  int taps = 9;                     // 9 (3x3, pad 1) or 1 (1x1)
+  int Cout = 0;                     // padded Cout (multiple of 32)
+  const float* emb = nullptr;       // optional per-(sample, cout) add: emb[n*emb_stride + co]
+  int emb_stride = 0;
+  const float* res = nullptr;       // optional residual NHWC [N,H,W,Cout]; may alias out
+  float* out = nullptr;             // NHWC [N,H,W,Cout], or NCHW [N,cout_valid,H,W] if out_nchw
+  int out_nchw = 0, cout_valid = 0;
+};
+int launch_conv(const ConvArgs& a, hipStream_t s);
+// repack PyTorch conv weight [Cout][Cin][kh][kw] -> [taps][CinP/4][CoutP][4] (zero padded)
+int launch_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int taps, int CoutP, int CinP, hipStream_t s);
+size_t packed_conv_weight_floats(int taps, int CoutP, int CinP);
+
+// GroupNorm statistics (gn.hip)
+// per-(n,c) first/second moments of an NHWC tensor: mom[n][c] = (mean, mean of squares)
+int launch_chan_moments(const float* x, int N, int HW, int C, double* partial /*[N][splits][C][2]*/, double2* mom /*[N][C]*/, hipStream_t s);
+int chan_moments_splits(int HW, int C);
+// combine moments of up to two concatenated sources into per-(n,c) scale/shift (32 groups, eps 1e-5)
+int launch_gn_finalize(const double2* mom0, int C0, const double2* mom1, int C1, const float* gamma, const float* beta, int N,
+                       float* scale, float* shift, hipStream_t s);
+
+// attention (attn.hip): qkv [N][T][3C] -> out [N][T][C]; scores workspace [N][T][T]
+int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s);
+
+// misc kernels (misc.hip)
+int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s);
+int launch_avgpool2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
+int launch_linear(const float* in, const float* w, const float* b, float* out, int N, int I, int O, int silu_in, int silu_out, hipStream_t s);
+int launch_timestep_embedding(const int64_t* t, const float* tf, float* out, int N, int dim, hipStream_t s);
+int launch_encoder_head(const float* x, const float* scale, const float* shift, const float* w, const float* b, float* out, int N, int HW,
+                        int C, int O, hipStream_t s);
+int launch_nhwc_to_nchw(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
+int launch_nchw_to_nhwc(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
+
+}  // namespace drm

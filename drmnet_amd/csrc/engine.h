@@ -1,0 +1,110 @@
+// Network engine: block topology, parameter table, packed-weight storage and the forward schedule of
+// kernel launches for the reference U-Net family (ldm/modules/diffusionmodules/openaimodel.py).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/drmnet_hip.h"
+#include "common.h"
+
+namespace drm {
+
+// Bump allocator over the caller's workspace; "dry" mode only measures (drm_unet_workspace_bytes).
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = false;
+  bool failed = false;
+  void* alloc_bytes(size_t bytes) {
+    const size_t a = (off + 255) & ~size_t(255);
+    off = a + bytes;
+    if (off > peak) peak = off;
+    if (dry) return nullptr;
+    if (off > cap) {
+      failed = true;
+      return nullptr;
+    }
+    return base + a;
+  }
+  template <typename T>
+  T* alloc(size_t n) {
+    return reinterpret_cast<T*>(alloc_bytes(n * sizeof(T)));
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+struct Act {  // NHWC activation (+ cached per-channel moments for GroupNorm)
+  float* p = nullptr;
+  int C = 0, H = 0, W = 0;  // stored size
+  int up = 0;               // logically nearest-x2 upsampled (consumer reads (y>>1, x>>1))
+  double2* mom = nullptr;   // [N][C] (mean, mean of squares)
+  bool mom_valid = false;
+};
+
+enum ParamKind { PK_COPY, PK_CONV };
+
+struct ParamSlot {
+  std::string name;
+  std::vector<int64_t> shape;
+  ParamKind kind = PK_COPY;
+  size_t dst = 0;          // float offset into the packed weight buffer
+  size_t count = 0;        // floats copied (PK_COPY)
+  int cout = 0, cin = 0, taps = 0, coutp = 0, cinp = 0;  // PK_CONV
+};
+
+struct ResLayer {
+  int cin = 0, cout = 0;
+  size_t n1_w = 0, n1_b = 0, c1_w = 0, c1_b = 0, n2_w = 0, n2_b = 0, c2_w = 0, c2_b = 0, sk_w = 0, sk_b = 0;
+  int emb_off = 0;  // column offset of this block's emb_layers output in the fused embedding buffer
+  bool has_skip = false;
+};
+struct AttnLayer {
+  int ch = 0;
+  size_t n_w = 0, n_b = 0, qkv_w = 0, qkv_b = 0, proj_w = 0, proj_b = 0;
+};
+struct Layer {
+  enum Kind { RES, ATTN, DOWN, UP } kind;
+  ResLayer res;
+  AttnLayer attn;
+};
+
+class UNet {
+ public:
+  drm_unet_desc desc{};
+  std::vector<ParamSlot> params;  // reference state_dict() order
+  std::vector<std::vector<Layer>> input_blocks, output_blocks;  // input_blocks[0] is the stem (empty list)
+  std::vector<Layer> middle;
+  int final_ch = 0, emb_dim = 0, emb_total = 0, in_cp = 0, out_cp = 0;
+  // packed-buffer offsets
+  size_t te0_w = 0, te0_b = 0, te2_w = 0, te2_b = 0, stem_w = 0, stem_b = 0, embcat_w = 0, embcat_b = 0, on_w = 0, on_b = 0, oc_w = 0, oc_b = 0;
+  size_t wbuf_floats = 0;
+  float* wbuf = nullptr;  // device
+  bool loaded = false;
+
+  int build(const drm_unet_desc& d);
+  int load(const float* const* ptrs, int count, hipStream_t s);
+  int forward(const float* x, int Cx, const float* cond, int Cc, const int32_t* rows, const float* t_emb, const int64_t* t, const float* tf,
+              float* out, int N, int H, int W, Arena& ar, hipStream_t s);
+  ~UNet();
+
+ private:
+  size_t add_copy(const std::string& name, std::vector<int64_t> shape, size_t padded_count = 0);
+  size_t add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d = false);
+  void add_res(Layer& l, const std::string& prefix, int cin, int cout);
+  void add_attn(Layer& l, const std::string& prefix, int ch);
+};
+
+// building blocks shared with the op-level ABI entry points
+struct Ctx {
+  Arena* ar;
+  hipStream_t s;
+  int N;
+  bool dry() const { return ar->dry; }
+};
+Act new_act(Ctx& c, int C, int H, int W);
+int ensure_moments(Ctx& c, Act& a);
+int run_resblock(Ctx& c, const float* wbuf, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out);
+int run_attention(Ctx& c, const float* wbuf, const AttnLayer& a, Act& x, Act& out);
+
+}  // namespace drm

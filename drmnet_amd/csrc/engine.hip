@@ -1,0 +1,424 @@
+// Network engine implementation (see engine.h).
+//
+// Topology enumeration restates the reference constructors (openaimodel.py:528-707 UNetModel,
+// :824-929 EncoderUNetModel) so that the parameter table equals the reference state_dict() order;
+// the forward schedule restates UNetModel.forward (:731-768) / EncoderUNetModel.forward (:969-991) as a
+// fixed list of kernel launches on one HIP stream, with
+//   * skip-concat and nearest-x2 upsample folded into the consumer's A-tile loader (never materialised),
+//   * GroupNorm+SiLU folded into the consumer conv, statistics cached per tensor,
+//   * all ResBlock emb_layers of the network evaluated by ONE linear launch per forward.
+#include "engine.h"
+
+#include <algorithm>
+#include <deque>
+
+namespace drm {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* last_error() { return g_err.c_str(); }
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+UNet::~UNet() {
+  if (wbuf) (void)hipFree(wbuf);
+}
+
+size_t UNet::add_copy(const std::string& name, std::vector<int64_t> shape, size_t padded_count) {
+  ParamSlot p;
+  p.name = name;
+  p.shape = shape;
+  p.kind = PK_COPY;
+  size_t cnt = 1;
+  for (auto v : shape) cnt *= (size_t)v;
+  p.count = cnt;
+  p.dst = wbuf_floats;
+  wbuf_floats += (std::max(cnt, padded_count) + 63) & ~size_t(63);
+  params.push_back(p);
+  return p.dst;
+}
+
+size_t UNet::add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d) {
+  ParamSlot p;
+  p.name = name;
+  if (conv1d) p.shape = {cout, cin, k};
+  else p.shape = {cout, cin, k, k};
+  p.kind = PK_CONV;
+  p.cout = cout; p.cin = cin; p.taps = conv1d ? k : k * k; p.coutp = coutp; p.cinp = cinp;
+  p.dst = wbuf_floats;
+  wbuf_floats += (packed_conv_weight_floats(p.taps, coutp, cinp) + 63) & ~size_t(63);
+  params.push_back(p);
+  return p.dst;
+}
+
+void UNet::add_res(Layer& l, const std::string& px, int cin, int cout) {
+  l.kind = Layer::RES;
+  ResLayer& r = l.res;
+  r.cin = cin; r.cout = cout; r.has_skip = (cin != cout);
+  r.n1_w = add_copy(px + ".in_layers.0.weight", {cin});
+  r.n1_b = add_copy(px + ".in_layers.0.bias", {cin});
+  r.c1_w = add_conv(px + ".in_layers.2.weight", cout, cin, 3, cout, cin);
+  r.c1_b = add_copy(px + ".in_layers.2.bias", {cout});
+  r.emb_off = emb_total;
+  emb_total += cout;
+  // emb_layers.1.{weight,bias}: destinations are fixed up once emb_total is known (fused [sum Cout][emb_dim] matrix)
+  ParamSlot ew; ew.name = px + ".emb_layers.1.weight"; ew.shape = {cout, emb_dim}; ew.kind = PK_COPY; ew.count = (size_t)cout * emb_dim; ew.dst = (size_t)-1; ew.cout = r.emb_off;
+  params.push_back(ew);
+  ParamSlot eb; eb.name = px + ".emb_layers.1.bias"; eb.shape = {cout}; eb.kind = PK_COPY; eb.count = (size_t)cout; eb.dst = (size_t)-2; eb.cout = r.emb_off;
+  params.push_back(eb);
+  r.n2_w = add_copy(px + ".out_layers.0.weight", {cout});
+  r.n2_b = add_copy(px + ".out_layers.0.bias", {cout});
+  r.c2_w = add_conv(px + ".out_layers.3.weight", cout, cout, 3, cout, cout);
+  r.c2_b = add_copy(px + ".out_layers.3.bias", {cout});
+  if (r.has_skip) {
+    r.sk_w = add_conv(px + ".skip_connection.weight", cout, cin, 1, cout, cin);
+    r.sk_b = add_copy(px + ".skip_connection.bias", {cout});
+  }
+}
+
+void UNet::add_attn(Layer& l, const std::string& px, int ch) {
+  l.kind = Layer::ATTN;
+  AttnLayer& a = l.attn;
+  a.ch = ch;
+  a.n_w = add_copy(px + ".norm.weight", {ch});
+  a.n_b = add_copy(px + ".norm.bias", {ch});
+  a.qkv_w = add_conv(px + ".qkv.weight", 3 * ch, ch, 1, 3 * ch, ch, true);
+  a.qkv_b = add_copy(px + ".qkv.bias", {3 * ch});
+  a.proj_w = add_conv(px + ".proj_out.weight", ch, ch, 1, ch, ch, true);
+  a.proj_b = add_copy(px + ".proj_out.bias", {ch});
+}
+
+int UNet::build(const drm_unet_desc& d) {
+  desc = d;
+  DRM_REQUIRE(d.kind == 0 || d.kind == 1, "kind must be 0 (UNetModel) or 1 (EncoderUNetModel)");
+  DRM_REQUIRE(d.n_levels >= 1 && d.n_levels <= DRM_MAX_LEVELS, "n_levels");
+  DRM_REQUIRE(d.n_attn >= 0 && d.n_attn <= DRM_MAX_LEVELS, "n_attn");
+  DRM_REQUIRE(d.model_channels > 0 && d.model_channels % 32 == 0, "model_channels must be a multiple of 32 (GroupNorm32)");
+  DRM_REQUIRE(d.in_channels > 0 && d.in_channels <= 32, "in_channels");
+  DRM_REQUIRE(d.out_channels > 0 && d.out_channels <= 32, "out_channels");
+  DRM_REQUIRE(d.num_res_blocks >= 1, "num_res_blocks");
+  const int mc = d.model_channels;
+  emb_dim = 4 * mc;
+  DRM_REQUIRE(emb_dim <= 512, "time_embed_dim (4*model_channels) must be <= 512");
+  in_cp = round_up(d.in_channels, 8);
+  out_cp = 32;
+  auto has_attn = [&](int ds) {
+    for (int i = 0; i < d.n_attn; ++i)
+      if (d.attention_resolutions[i] == ds) return true;
+    return false;
+  };
+
+  te0_w = add_copy("time_embed.0.weight", {emb_dim, mc});
+  te0_b = add_copy("time_embed.0.bias", {emb_dim});
+  te2_w = add_copy("time_embed.2.weight", {emb_dim, emb_dim});
+  te2_b = add_copy("time_embed.2.bias", {emb_dim});
+  stem_w = add_conv("input_blocks.0.0.weight", mc, d.in_channels, 3, mc, in_cp);
+  stem_b = add_copy("input_blocks.0.0.bias", {mc});
+  input_blocks.emplace_back();
+
+  std::vector<int> chans{mc};
+  int ch = mc, ds = 1, idx = 1;
+  for (int level = 0; level < d.n_levels; ++level) {
+    const int m = d.channel_mult[level];
+    DRM_REQUIRE(m >= 1, "channel_mult");
+    for (int k = 0; k < d.num_res_blocks; ++k) {
+      std::vector<Layer> ls(1);
+      add_res(ls[0], "input_blocks." + std::to_string(idx) + ".0", ch, m * mc);
+      ch = m * mc;
+      if (has_attn(ds)) {
+        ls.emplace_back();
+        add_attn(ls.back(), "input_blocks." + std::to_string(idx) + ".1", ch);
+      }
+      input_blocks.push_back(ls);
+      chans.push_back(ch);
+      ++idx;
+    }
+    if (level != d.n_levels - 1) {
+      std::vector<Layer> ls(1);
+      ls[0].kind = Layer::DOWN;
+      input_blocks.push_back(ls);
+      chans.push_back(ch);
+      ++idx;
+      ds *= 2;
+    }
+  }
+  middle.resize(3);
+  add_res(middle[0], "middle_block.0", ch, ch);
+  add_attn(middle[1], "middle_block.1", ch);
+  add_res(middle[2], "middle_block.2", ch, ch);
+  if (d.kind == 0) {
+    int oidx = 0;
+    for (int level = d.n_levels - 1; level >= 0; --level) {
+      const int m = d.channel_mult[level];
+      for (int i = 0; i <= d.num_res_blocks; ++i) {
+        const int ich = chans.back();
+        chans.pop_back();
+        std::vector<Layer> ls(1);
+        add_res(ls[0], "output_blocks." + std::to_string(oidx) + ".0", ch + ich, mc * m);
+        ch = mc * m;
+        if (has_attn(ds)) {
+          ls.emplace_back();
+          add_attn(ls.back(), "output_blocks." + std::to_string(oidx) + ".1", ch);
+        }
+        if (level && i == d.num_res_blocks) {
+          ls.emplace_back();
+          ls.back().kind = Layer::UP;
+          ds /= 2;
+        }
+        output_blocks.push_back(ls);
+        ++oidx;
+      }
+    }
+  }
+  final_ch = ch;
+  on_w = add_copy("out.0.weight", {ch});
+  on_b = add_copy("out.0.bias", {ch});
+  if (d.kind == 0) {
+    DRM_REQUIRE(ch == mc, "UNetModel head expects model_channels inputs");
+    oc_w = add_conv("out.2.weight", d.out_channels, mc, 3, out_cp, mc);
+    oc_b = add_copy("out.2.bias", {d.out_channels}, out_cp);
+  } else {
+    oc_w = add_copy("out.3.weight", {d.out_channels, ch, 1, 1});
+    oc_b = add_copy("out.3.bias", {d.out_channels});
+  }
+  // fused embedding projection
+  embcat_w = wbuf_floats;
+  wbuf_floats += ((size_t)emb_total * emb_dim + 63) & ~size_t(63);
+  embcat_b = wbuf_floats;
+  wbuf_floats += ((size_t)emb_total + 63) & ~size_t(63);
+  for (auto& p : params) {
+    if (p.dst == (size_t)-1) p.dst = embcat_w + (size_t)p.cout * emb_dim;
+    else if (p.dst == (size_t)-2) p.dst = embcat_b + (size_t)p.cout;
+  }
+  return DRM_OK;
+}
+
+int UNet::load(const float* const* ptrs, int count, hipStream_t s) {
+  DRM_REQUIRE(count == (int)params.size(), "parameter count mismatch: got " + std::to_string(count) + ", expected " + std::to_string(params.size()));
+  if (!wbuf) DRM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wbuf), wbuf_floats * sizeof(float)));
+  DRM_HIP_CHECK(hipMemsetAsync(wbuf, 0, wbuf_floats * sizeof(float), s));
+  for (size_t i = 0; i < params.size(); ++i) {
+    const ParamSlot& p = params[i];
+    DRM_REQUIRE(ptrs[i] != nullptr, "null parameter pointer for " + p.name);
+    if (p.kind == PK_COPY) {
+      DRM_HIP_CHECK(hipMemcpyAsync(wbuf + p.dst, ptrs[i], p.count * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+      DRM_TRY(launch_pack_conv_weight(ptrs[i], wbuf + p.dst, p.cout, p.cin, p.taps, p.coutp, p.cinp, s));
+    }
+  }
+  loaded = true;
+  return DRM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ blocks
+
+Act new_act(Ctx& c, int C, int H, int W) {
+  Act a;
+  a.C = C; a.H = H; a.W = W;
+  a.p = c.ar->alloc<float>((size_t)c.N * H * W * C);
+  a.mom = c.ar->alloc<double2>((size_t)c.N * C);
+  return a;
+}
+
+int ensure_moments(Ctx& c, Act& a) {
+  if (a.mom_valid) return DRM_OK;
+  const int hs = a.H >> a.up, ws = a.W >> a.up;
+  const size_t m = c.ar->mark();
+  const int splits = chan_moments_splits(hs * ws, a.C);
+  double* partial = c.ar->alloc<double>((size_t)c.N * splits * a.C * 2);
+  if (!c.dry()) DRM_TRY(launch_chan_moments(a.p, c.N, hs * ws, a.C, partial, a.mom, c.s));
+  c.ar->release(m);
+  a.mom_valid = true;
+  return DRM_OK;
+}
+
+int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out) {
+  const int H = x0.H, W = x0.W;
+  const int C0 = x0.C, C1 = x1 ? x1->C : 0;
+  DRM_REQUIRE(C0 + C1 == r.cin, "resblock input channels");
+  DRM_REQUIRE(!x1 || (x1->H == H && x1->W == W && !x1->up), "resblock skip tensor shape");
+  DRM_REQUIRE(r.has_skip || (!x1 && !x0.up), "identity skip on a concatenated / upsampled input is not supported");
+  const size_t mark = c.ar->mark();
+  DRM_TRY(ensure_moments(c, x0));
+  if (x1) DRM_TRY(ensure_moments(c, *x1));
+  float* sc1 = c.ar->alloc<float>((size_t)c.N * r.cin);
+  float* sh1 = c.ar->alloc<float>((size_t)c.N * r.cin);
+  Act h1 = new_act(c, r.cout, H, W);
+  float* sc2 = c.ar->alloc<float>((size_t)c.N * r.cout);
+  float* sh2 = c.ar->alloc<float>((size_t)c.N * r.cout);
+  if (!c.dry()) {
+    DRM_TRY(launch_gn_finalize(x0.mom, C0, x1 ? x1->mom : nullptr, C1, Wb + r.n1_w, Wb + r.n1_b, c.N, sc1, sh1, c.s));
+    ConvArgs a;
+    a.src0 = x0.p; a.src1 = x1 ? x1->p : nullptr; a.C0 = C0; a.C1 = C1; a.up0 = x0.up;
+    a.N = c.N; a.H = H; a.W = W;
+    a.gn_scale = sc1; a.gn_shift = sh1; a.silu = 1;
+    a.w = Wb + r.c1_w; a.bias = Wb + r.c1_b; a.taps = 9; a.Cout = r.cout;
+    a.emb = emb_all ? emb_all + r.emb_off : nullptr; a.emb_stride = emb_stride;
+    a.out = h1.p;
+    DRM_TRY(launch_conv(a, c.s));
+  }
+  DRM_TRY(ensure_moments(c, h1));
+  if (!c.dry()) {
+    DRM_TRY(launch_gn_finalize(h1.mom, r.cout, nullptr, 0, Wb + r.n2_w, Wb + r.n2_b, c.N, sc2, sh2, c.s));
+    const float* res = x0.p;
+    if (r.has_skip) {
+      ConvArgs k;
+      k.src0 = x0.p; k.src1 = x1 ? x1->p : nullptr; k.C0 = C0; k.C1 = C1; k.up0 = x0.up;
+      k.N = c.N; k.H = H; k.W = W;
+      k.w = Wb + r.sk_w; k.bias = Wb + r.sk_b; k.taps = 1; k.Cout = r.cout;
+      k.out = out.p;
+      DRM_TRY(launch_conv(k, c.s));
+      res = out.p;
+    }
+    ConvArgs b;
+    b.src0 = h1.p; b.C0 = r.cout; b.N = c.N; b.H = H; b.W = W;
+    b.gn_scale = sc2; b.gn_shift = sh2; b.silu = 1;
+    b.w = Wb + r.c2_w; b.bias = Wb + r.c2_b; b.taps = 9; b.Cout = r.cout;
+    b.res = res; b.out = out.p;
+    DRM_TRY(launch_conv(b, c.s));
+  }
+  c.ar->release(mark);
+  return DRM_OK;
+}
+
+int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out) {
+  DRM_REQUIRE(!x.up && x.C == l.ch, "attention input");
+  const int H = x.H, W = x.W, T = H * W, C = l.ch;
+  const size_t mark = c.ar->mark();
+  DRM_TRY(ensure_moments(c, x));
+  float* sc = c.ar->alloc<float>((size_t)c.N * C);
+  float* sh = c.ar->alloc<float>((size_t)c.N * C);
+  float* qkv = c.ar->alloc<float>((size_t)c.N * T * 3 * C);
+  float* scores = c.ar->alloc<float>((size_t)c.N * T * T);
+  float* att = c.ar->alloc<float>((size_t)c.N * T * C);
+  if (!c.dry()) {
+    DRM_TRY(launch_gn_finalize(x.mom, C, nullptr, 0, Wb + l.n_w, Wb + l.n_b, c.N, sc, sh, c.s));
+    ConvArgs a;
+    a.src0 = x.p; a.C0 = C; a.N = c.N; a.H = H; a.W = W;
+    a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
+    a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.taps = 1; a.Cout = 3 * C; a.out = qkv;
+    DRM_TRY(launch_conv(a, c.s));
+    DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s));
+    ConvArgs p;
+    p.src0 = att; p.C0 = C; p.N = c.N; p.H = H; p.W = W;
+    p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.taps = 1; p.Cout = C; p.res = x.p; p.out = out.p;
+    DRM_TRY(launch_conv(p, c.s));
+  }
+  c.ar->release(mark);
+  return DRM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+
+int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32_t* rows, const float* t_emb, const int64_t* t,
+                  const float* tf, float* out, int N, int H, int W, Arena& ar, hipStream_t s) {
+  DRM_REQUIRE(ar.dry || loaded, "drm_unet_forward before drm_unet_load_params");
+  DRM_REQUIRE(N > 0, "batch size");
+  DRM_REQUIRE(Cx + Cc == desc.in_channels, "x/cond channels must sum to in_channels");
+  const int down = 1 << (desc.n_levels - 1);
+  DRM_REQUIRE(H % (4 * down) == 0 && W % (4 * down) == 0,
+              "H and W must be multiples of " + std::to_string(4 * down) + " (4x4 minimum feature map at the deepest level)");
+  const int n_t = (t_emb != nullptr) + (t != nullptr) + (tf != nullptr);
+  if (!ar.dry) {
+    if (desc.kind == 0) DRM_REQUIRE(n_t == 1, "timesteps and t_emb cannot be specified at the same time");
+    else DRM_REQUIRE(n_t == 1 && t_emb == nullptr, "EncoderUNetModel takes timesteps");
+  }
+  Ctx c{&ar, s, N};
+  const float* Wb = wbuf;
+  const int mc = desc.model_channels;
+
+  Act xin = new_act(c, in_cp, H, W);
+  float* temb = c.ar->alloc<float>((size_t)N * mc);
+  float* e1 = c.ar->alloc<float>((size_t)N * emb_dim);
+  float* emb = c.ar->alloc<float>((size_t)N * emb_dim);
+  float* emb_all = c.ar->alloc<float>((size_t)N * emb_total);
+  if (!c.dry()) {
+    DRM_TRY(launch_pack_input(x, cond, rows, xin.p, N, H, W, Cx, Cc, in_cp, s));
+    const float* te = t_emb;
+    if (!te) {
+      DRM_TRY(launch_timestep_embedding(t, tf, temb, N, mc, s));
+      te = temb;
+    }
+    DRM_TRY(launch_linear(te, Wb + te0_w, Wb + te0_b, e1, N, mc, emb_dim, 0, 1, s));
+    DRM_TRY(launch_linear(e1, Wb + te2_w, Wb + te2_b, emb, N, emb_dim, emb_dim, 0, 0, s));
+    DRM_TRY(launch_linear(emb, Wb + embcat_w, Wb + embcat_b, emb_all, N, emb_dim, emb_total, 1, 0, s));
+  }
+
+  std::deque<Act> acts;  // stable addresses: the skip stack and `h` share cached GroupNorm moments
+  auto make = [&](int C_, int H_, int W_) -> Act* {
+    acts.push_back(new_act(c, C_, H_, W_));
+    return &acts.back();
+  };
+  std::vector<Act*> hs;
+  Act* h = make(mc, H, W);
+  if (!c.dry()) {
+    ConvArgs a;
+    a.src0 = xin.p; a.C0 = in_cp; a.N = N; a.H = H; a.W = W;
+    a.w = Wb + stem_w; a.bias = Wb + stem_b; a.taps = 9; a.Cout = mc; a.out = h->p;
+    DRM_TRY(launch_conv(a, s));
+  }
+  hs.push_back(h);
+
+  auto run_layers = [&](std::vector<Layer>& ls, Act* skip) -> int {
+    for (size_t li = 0; li < ls.size(); ++li) {
+      Layer& l = ls[li];
+      if (l.kind == Layer::RES) {
+        Act* o = make(l.res.cout, h->H, h->W);
+        DRM_TRY(run_resblock(c, Wb, l.res, *h, (li == 0) ? skip : nullptr, emb_all, emb_total, *o));
+        h = o;
+      } else if (l.kind == Layer::ATTN) {
+        Act* o = make(l.attn.ch, h->H, h->W);
+        DRM_TRY(run_attention(c, Wb, l.attn, *h, *o));
+        h = o;
+      } else if (l.kind == Layer::DOWN) {
+        DRM_REQUIRE(!h->up, "downsample of an upsampled tensor");
+        Act* o = make(h->C, h->H / 2, h->W / 2);
+        if (!c.dry()) DRM_TRY(launch_avgpool2(h->p, o->p, N, h->H, h->W, h->C, s));
+        h = o;
+      } else {  // UP: nearest x2, folded into the consumer (moments are unchanged by replication)
+        DRM_REQUIRE(!h->up, "double upsample");
+        h->up = 1;
+        h->H *= 2;
+        h->W *= 2;
+      }
+    }
+    return DRM_OK;
+  };
+
+  for (size_t b = 1; b < input_blocks.size(); ++b) {
+    DRM_TRY(run_layers(input_blocks[b], nullptr));
+    hs.push_back(h);
+  }
+  DRM_TRY(run_layers(middle, nullptr));
+  for (auto& blk : output_blocks) {
+    Act* skip = hs.back();
+    hs.pop_back();
+    DRM_TRY(run_layers(blk, skip));
+  }
+
+  // head
+  DRM_REQUIRE(!h->up && h->C == final_ch, "head input");
+  DRM_TRY(ensure_moments(c, *h));
+  float* sc = c.ar->alloc<float>((size_t)N * final_ch);
+  float* sh = c.ar->alloc<float>((size_t)N * final_ch);
+  if (!c.dry()) {
+    DRM_TRY(launch_gn_finalize(h->mom, final_ch, nullptr, 0, Wb + on_w, Wb + on_b, N, sc, sh, s));
+    if (desc.kind == 0) {
+      ConvArgs a;
+      a.src0 = h->p; a.C0 = final_ch; a.N = N; a.H = h->H; a.W = h->W;
+      a.gn_scale = sc; a.gn_shift = sh; a.silu = 1;
+      a.w = Wb + oc_w; a.bias = Wb + oc_b; a.taps = 9; a.Cout = out_cp;
+      a.out = out; a.out_nchw = 1; a.cout_valid = desc.out_channels;
+      DRM_TRY(launch_conv(a, s));
+    } else {
+      DRM_TRY(launch_encoder_head(h->p, sc, sh, Wb + oc_w, Wb + oc_b, out, N, h->H * h->W, final_ch, desc.out_channels, s));
+    }
+  }
+  if (ar.failed) {
+    set_error("workspace too small: need " + std::to_string(ar.peak) + " bytes, got " + std::to_string(ar.cap));
+    return DRM_ERR_WORKSPACE;
+  }
+  return DRM_OK;
+}
+
+}  // namespace drm

@@ -1,0 +1,127 @@
+// GroupNorm32 statistics for NHWC activations (reference: ldm/modules/diffusionmodules/util.py:199-216,
+// torch.nn.GroupNorm with 32 groups, eps 1e-5, biased variance, fp32).
+//
+// The norm itself is never materialised: the consumer (conv.hip A-tile loader, misc.hip encoder head)
+// applies  y = x * scale[n][c] + shift[n][c]  with scale = rstd*gamma, shift = beta - mean*rstd*gamma.
+// Statistics are kept per CHANNEL ((mean, mean of squares) per (sample, channel)) so that
+//   * a tensor's moments are computed once and reused by every GroupNorm that sees it (encoder output ->
+//     next block AND the decoder concat);
+//   * the concat of two tensors (openaimodel.py:762) and the nearest-x2 upsample (:116; replication leaves
+//     per-channel moments unchanged) need no data pass at all: groups that straddle the concat boundary
+//     are assembled from the two moment tables in gn_finalize.
+// HBM-bound pass: reads the tensor once with 16-B/lane coalesced loads; wave/LDS tree reductions, partial
+// sums per slab, final accumulation in double.
+#include "common.h"
+
+namespace drm {
+
+int chan_moments_splits(int HW, int C) {
+  int s = HW / 64;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+// grid (splits, N), block (64, 4): x = channel quad within a 64-quad block, y = pixel lane
+__global__ __launch_bounds__(256) void chan_moments_partial_kernel(const float* __restrict__ x, int HW, int C, int splits,
+                                                                    double* __restrict__ partial) {
+  __shared__ double red[2][4][64][4];
+  const int s = blockIdx.x, n = blockIdx.y;
+  const int qx = threadIdx.x, py = threadIdx.y;
+  const int q4 = C >> 2;
+  const int p0 = (int)(((long long)HW * s) / splits), p1 = (int)(((long long)HW * (s + 1)) / splits);
+  const float4* xp = reinterpret_cast<const float4*>(x) + (size_t)n * HW * q4;
+  for (int qb = 0; qb < q4; qb += 64) {
+    const int q = qb + qx;
+    // double accumulation: var = E[x^2] - E[x]^2 cancels badly in fp32 when |mean| >> std
+    double sum[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+    if (q < q4) {
+      for (int p = p0 + py; p < p1; p += 4) {
+        const float4 v = xp[(size_t)p * q4 + q];
+        sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+        sq[0] += (double)v.x * v.x; sq[1] += (double)v.y * v.y; sq[2] += (double)v.z * v.z; sq[3] += (double)v.w * v.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[0][py][qx][k] = sum[k];
+      red[1][py][qx][k] = sq[k];
+    }
+    __syncthreads();
+    if (py == 0 && q < q4) {
+      double* o = partial + (((size_t)n * splits + s) * C + 4 * q) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[2 * k] = red[0][0][qx][k] + red[0][1][qx][k] + red[0][2][qx][k] + red[0][3][qx][k];
+        o[2 * k + 1] = red[1][0][qx][k] + red[1][1][qx][k] + red[1][2][qx][k] + red[1][3][qx][k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void chan_moments_reduce_kernel(const double* __restrict__ partial, int N, int C, int splits, double inv_hw, double2* __restrict__ mom) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < splits; ++k) {
+    const double* p = partial + (((size_t)n * splits + k) * C + c) * 2;
+    s += p[0];
+    q += p[1];
+  }
+  mom[i] = make_double2(s * inv_hw, q * inv_hw);
+}
+
+int launch_chan_moments(const float* x, int N, int HW, int C, double* partial, double2* mom, hipStream_t s) {
+  DRM_REQUIRE(C % 4 == 0, "chan_moments: C % 4");
+  const int splits = chan_moments_splits(HW, C);
+  hipLaunchKernelGGL(chan_moments_partial_kernel, dim3(splits, N), dim3(64, 4), 0, s, x, HW, C, splits, partial);
+  DRM_HIP_CHECK(hipGetLastError());
+  const int total = N * C;
+  hipLaunchKernelGGL(chan_moments_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, partial, N, C, splits, 1.0 / (double)HW, mom);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
+// grid N, block 256.  32 groups over the concatenated channel axis [C0 | C1].
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restrict__ mom0, int C0, const double2* __restrict__ mom1, int C1,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ float g_mean[32], g_rstd[32];
+  const int n = blockIdx.x;
+  const int C = C0 + C1, cpg = C / 32;
+  const int t = threadIdx.x;
+  if (t < 32) {
+    double m = 0.0, q = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      const int c = t * cpg + k;
+      const double2 v = (c < C0) ? mom0[(size_t)n * C0 + c] : mom1[(size_t)n * C1 + (c - C0)];
+      m += v.x;
+      q += v.y;
+    }
+    m /= cpg;
+    q /= cpg;
+    double var = q - m * m;
+    if (var < 0.0) var = 0.0;
+    g_mean[t] = (float)m;
+    g_rstd[t] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = g_rstd[g] * gamma[c];
+    scale[(size_t)n * C + c] = sc;
+    shift[(size_t)n * C + c] = beta[c] - g_mean[g] * sc;
+  }
+}
+
+int launch_gn_finalize(const double2* mom0, int C0, const double2* mom1, int C1, const float* gamma, const float* beta, int N, float* scale,
+                       float* shift, hipStream_t s) {
+  DRM_REQUIRE((C0 + C1) % 32 == 0, "GroupNorm32 needs channels % 32 == 0");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, mom0, C0, mom1, C1, gamma, beta, scale, shift);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
+}  // namespace drm

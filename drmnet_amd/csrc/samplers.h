@@ -1,0 +1,39 @@
+// Sampler drivers (see samplers.hip).
+#pragma once
+#include "engine.h"
+
+namespace drm {
+
+int launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+
+class DrmnetSampler {
+ public:
+  UNet* illnet = nullptr;
+  UNet* refnet = nullptr;
+  drm_drmnet_cfg cfg{};
+  int init(UNet* ill, UNet* ref, const float* const* zemb_params, const drm_drmnet_cfg& c);
+  size_t workspace_bytes(int N, int H, int W) const;
+  int step(float* Lr_k, const float* LrK, const int32_t* rows, int n, int i, const float* noise, uint64_t seed, float* zk_out, float* zK_out,
+           int32_t* conv_out, int B, int H, int W, Arena& ar, hipStream_t s);
+  int sample(const float* LrK, const float* noise0, const float* step_noise, uint64_t seed, int early_exit, float* Lr0, float* zK, int32_t* K,
+             int32_t* steps_done, int B, int H, int W, Arena& ar, hipStream_t s);
+  ~DrmnetSampler();
+
+ private:
+  float* zemb = nullptr;  // z_emb_layer.{0,2,4}.{weight,bias}, device copy
+  size_t zoff[6] = {0, 0, 0, 0, 0, 0};
+  float* z0_dev = nullptr;
+  int32_t* h_rows = nullptr;  // pinned staging for the active-row list / convergence flags
+  int32_t* h_conv = nullptr;
+  int h_cap = 0;
+  int32_t* last = nullptr;  // device convergence flags / clamped zK of the most recent step (inside the workspace)
+  float* last_zKc = nullptr;
+};
+
+size_t sampler_workspace_bytes(UNet* net, int N, int H, int W);
+int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s);
+int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip, const float* noise,
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s);
+
+}  // namespace drm

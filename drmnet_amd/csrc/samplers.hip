@@ -1,0 +1,375 @@
+// Sampler loops on the device: DRMNet's residual reverse process, DDIM and ancestral DDPM.
+//
+// Reference semantics restated (paths relative to the reference root):
+//   DRMNet.p_sample_loop / forward / get_brdf_out / get_schedule / check_convergence
+//       models/drmnet.py:782-847, :452-456, :390-396, :458-501, :747-750
+//   DDIMSampler.ddim_sampling / p_sample_ddim     ldm/models/diffusion/ddim.py:128-259
+//   LatentDiffusion.p_sample / p_mean_variance    ldm/models/diffusion/ddpm.py:1079-1167
+//   ObsNetDiffusion.p_sample_loop                 models/obsnet.py:500-564
+// Each sampler step is: U-Net forward(s) (engine) + ONE fused elementwise update kernel here.
+// Noise is either an external buffer (parity mode; the reference's draws are data dependent) or the
+// library's counter-based Philox4x32-10 stream (throughput mode), selected by a null pointer.
+#include "samplers.h"
+
+#include <cmath>
+#include <vector>
+
+namespace drm {
+
+// ------------------------------------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t ctr) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float s = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)c[0] + 0.5f) * s, u1 = ((float)c[1] + 0.5f) * s;
+  const float u2 = ((float)c[2] + 0.5f) * s, u3 = ((float)c[3] + 0.5f) * s;
+  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+}
+__device__ __forceinline__ float philox_normal1(uint64_t seed, uint64_t elem) {
+  const float4 v = philox_normal4(seed, elem >> 2);
+  const int k = (int)(elem & 3);
+  return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+}
+
+__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = philox_normal1(seed, offset + i);
+}
+int launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
+  if (n == 0) return DRM_OK;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, seed, offset);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
+__global__ void fill_f32_kernel(float* p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void fill_i32_kernel(int32_t* p, size_t n, int32_t v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+static int fill_f32(float* p, size_t n, float v, hipStream_t s) {
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+static int fill_i32(int32_t* p, size_t n, int32_t v, hipStream_t s) {
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ DRMNet kernels
+
+// Lr_k = LrK + delta * eps0   (models/drmnet.py:796-797)
+__global__ void drmnet_init_kernel(const float* __restrict__ LrK, const float* __restrict__ noise0, float* __restrict__ Lr_k, size_t n,
+                                   float delta, uint64_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float e = noise0 ? noise0[i] : philox_normal1(seed, i);
+  Lr_k[i] = LrK[i] + delta * e;
+}
+
+// get_brdf_out (eval) + check_convergence: zk = clamp(z0 + gpow (z_out - z0), 0, 1); zK = clamp(z_out, 0, 1);
+// dz = zk - z0; conv = ||zk - z0||_2 < eps or == 0.  gpow = float(exp(i * ln(gamma))) evaluated in fp64 on the host
+// (models/drmnet.py:494-495).
+__global__ void drmnet_brdf_kernel(const float* __restrict__ z_out, const float* __restrict__ z0, int n, int zd, float gpow, float eps,
+                                   float* __restrict__ zk, float* __restrict__ dz, float* __restrict__ zKc, int32_t* __restrict__ conv) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float d2 = 0.f;
+  for (int k = 0; k < zd; ++k) {
+    const float zo = z_out[j * zd + k], z = z0[k];
+    float v = gpow * (zo - z) + z;
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    const float d = v - z;
+    zk[j * zd + k] = v;
+    dz[j * zd + k] = d;
+    zKc[j * zd + k] = fminf(fmaxf(zo, 0.f), 1.f);
+    d2 += fabsf(d) * fabsf(d);
+  }
+  const float dist = sqrtf(d2);
+  conv[j] = (dist < eps || dist == 0.f) ? 1 : 0;
+}
+
+// Lr_k[rows[j]] += out[j] (+ delta * noise[rows[j]] unless converged)   (models/drmnet.py:763,822-825)
+__global__ void drmnet_update_kernel(float* __restrict__ Lr_k, const float* __restrict__ out, const int32_t* __restrict__ rows,
+                                     const int32_t* __restrict__ conv, const float* __restrict__ noise, int n, size_t chw, float delta,
+                                     uint64_t seed, uint64_t noise_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n * chw) return;
+  const int j = (int)(i / chw);
+  const size_t e = i % chw;
+  const int row = rows ? rows[j] : j;
+  const size_t g = (size_t)row * chw + e;
+  float v = Lr_k[g] + out[i];
+  if (!conv[j]) {
+    const float nz = noise ? noise[g] : philox_normal1(seed, noise_off + g);
+    v += nz * delta;
+  }
+  Lr_k[g] = v;
+}
+
+// K[rows[j]] = step + 1; zK[rows[j]] = zKc[j] for rows that converged this step (models/drmnet.py:836-838)
+__global__ void drmnet_record_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ conv, const float* __restrict__ zKc, int n,
+                                     int zd, int step, float* __restrict__ zK, int32_t* __restrict__ K) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || !conv[j]) return;
+  const int row = rows ? rows[j] : j;
+  K[row] = step + 1;
+  for (int k = 0; k < zd; ++k) zK[row * zd + k] = zKc[j * zd + k];
+}
+
+// ------------------------------------------------------------------------------------------------ DDIM / DDPM kernels
+
+// pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);  x = sqrt(a_prev) pred_x0 + sqrt(1-a_prev-s^2) e + s * noise   (ddim.py:249-258)
+__global__ void ddim_update_kernel(float* __restrict__ x, const float* __restrict__ e, const float* __restrict__ noise, size_t n, float sa,
+                                   float s1m, float sap, float sdir, float sig, uint64_t seed, uint64_t noise_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i], ev = e[i];
+  const float pred = (xv - s1m * ev) / sa;
+  float nz = 0.f;
+  if (sig != 0.f) nz = noise ? noise[i] : philox_normal1(seed, noise_off + i);
+  x[i] = sap * pred + sdir * ev + sig * nz;
+}
+
+// x_recon = c0 x - c1 e; mean = c2 x_recon + c3 x; x = mean + [t>0] c4 noise   (ddpm.py:233-246,1156-1167)
+__global__ void ddpm_update_kernel(float* __restrict__ x, float* __restrict__ pred_x0, const float* __restrict__ e,
+                                   const float* __restrict__ noise, size_t n, float c0, float c1, float c2, float c3, float c4, int nonzero,
+                                   int clip, uint64_t seed, uint64_t noise_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i];
+  float xr = c0 * xv - c1 * e[i];
+  if (clip) xr = fminf(fmaxf(xr, -1.f), 1.f);
+  const float mean = c2 * xr + c3 * xv;
+  float v = mean;
+  if (nonzero) {
+    const float nz = noise ? noise[i] : philox_normal1(seed, noise_off + i);
+    v += c4 * nz;
+  }
+  x[i] = v;
+  if (pred_x0) pred_x0[i] = xr;
+}
+
+// ------------------------------------------------------------------------------------------------ DRMNet sampler
+
+DrmnetSampler::~DrmnetSampler() {
+  if (zemb) (void)hipFree(zemb);
+  if (z0_dev) (void)hipFree(z0_dev);
+  if (h_rows) (void)hipHostFree(h_rows);
+  if (h_conv) (void)hipHostFree(h_conv);
+}
+
+int DrmnetSampler::init(UNet* ill, UNet* ref, const float* const* zw, const drm_drmnet_cfg& c) {
+  DRM_REQUIRE(ill && ref && ill->desc.kind == 0 && ref->desc.kind == 1, "drmnet needs a UNetModel (IllNet) and an EncoderUNetModel (RefNet)");
+  DRM_REQUIRE(c.z_dim >= 1 && c.z_dim <= 8 && ref->desc.out_channels == c.z_dim, "z_dim must match RefNet out_channels (<= 8)");
+  DRM_REQUIRE(c.max_timesteps >= 1, "max_timesteps");
+  illnet = ill; refnet = ref; cfg = c;
+  const int mc = ill->desc.model_channels, hd = mc / 2;
+  const size_t sizes[6] = {(size_t)hd * c.z_dim, (size_t)hd, (size_t)hd * hd, (size_t)hd, (size_t)mc * hd, (size_t)mc};
+  size_t total = 0;
+  for (int i = 0; i < 6; ++i) { zoff[i] = total; total += (sizes[i] + 63) & ~size_t(63); }
+  DRM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&zemb), total * sizeof(float)));
+  for (int i = 0; i < 6; ++i) {
+    DRM_REQUIRE(zw[i] != nullptr, "null z_emb_layer parameter");
+    DRM_HIP_CHECK(hipMemcpy(zemb + zoff[i], zw[i], sizes[i] * sizeof(float), hipMemcpyDeviceToDevice));
+  }
+  DRM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&z0_dev), 8 * sizeof(float)));
+  DRM_HIP_CHECK(hipMemcpy(z0_dev, c.z0, 8 * sizeof(float), hipMemcpyHostToDevice));
+  return DRM_OK;
+}
+
+struct StepBuffers {
+  float *z_out, *zk, *dz, *zKc, *h1, *h2, *temb, *tf, *eps;
+  int32_t* conv;
+};
+static StepBuffers step_buffers(Arena& ar, int n, int zd, int mc, size_t chw) {
+  StepBuffers b;
+  b.z_out = ar.alloc<float>((size_t)n * zd);
+  b.zk = ar.alloc<float>((size_t)n * zd);
+  b.dz = ar.alloc<float>((size_t)n * zd);
+  b.zKc = ar.alloc<float>((size_t)n * zd);
+  b.h1 = ar.alloc<float>((size_t)n * (mc / 2));
+  b.h2 = ar.alloc<float>((size_t)n * (mc / 2));
+  b.temb = ar.alloc<float>((size_t)n * mc);
+  b.tf = ar.alloc<float>((size_t)n);
+  b.conv = ar.alloc<int32_t>((size_t)n);
+  b.eps = ar.alloc<float>((size_t)n * chw);
+  return b;
+}
+
+size_t DrmnetSampler::workspace_bytes(int N, int H, int W) const {
+  Arena ar;
+  ar.dry = true;
+  step_buffers(ar, N, cfg.z_dim, illnet->desc.model_channels, (size_t)3 * H * W);
+  ar.alloc<int32_t>((size_t)N);  // rows
+  ar.alloc_bytes(0);
+  const size_t base = (ar.peak + 255) & ~size_t(255);
+  Arena a1; a1.dry = true;
+  Arena a2; a2.dry = true;
+  if (illnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a1, nullptr) != DRM_OK) return 0;
+  if (refnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a2, nullptr) != DRM_OK) return 0;
+  return base + std::max(a1.peak, a2.peak) + 256;
+}
+
+// One reverse step on rows[0..n) (device indices, or null = identity)
+int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int n, int i, const float* noise, uint64_t seed, float* zk_out,
+                        float* zK_out, int32_t* conv_out, int B, int H, int W, Arena& ar, hipStream_t s) {
+  DRM_REQUIRE(n >= 1 && n <= B, "n_active");
+  const int zd = cfg.z_dim, mc = illnet->desc.model_channels, hd = mc / 2;
+  const size_t chw = (size_t)3 * H * W;
+  StepBuffers b = step_buffers(ar, n, zd, mc, chw);
+  if (ar.failed) { set_error("drmnet step: workspace too small"); return DRM_ERR_WORKSPACE; }
+  const size_t net_mark = ar.mark();
+  // RefNet(cat[Lr_k, LrK], timesteps = i)     (models/drmnet.py:453, :376-388)
+  DRM_TRY(fill_f32(b.tf, n, (float)i, s));
+  DRM_TRY(refnet->forward(Lr_k, 3, LrK, 3, rows, nullptr, nullptr, b.tf, b.z_out, n, H, W, ar, s));
+  ar.release(net_mark);
+  const float gpow = (float)std::exp((double)i * std::log(cfg.gamma));
+  hipLaunchKernelGGL(drmnet_brdf_kernel, dim3((n + 63) / 64), dim3(64), 0, s, b.z_out, z0_dev, n, zd, gpow, cfg.epsilon, b.zk, b.dz, b.zKc, b.conv);
+  DRM_HIP_CHECK(hipGetLastError());
+  // z_emb_layer(zk - z0): Linear-SiLU x3   (models/drmnet.py:38-45,55)
+  DRM_TRY(launch_linear(b.dz, zemb + zoff[0], zemb + zoff[1], b.h1, n, zd, hd, 0, 1, s));
+  DRM_TRY(launch_linear(b.h1, zemb + zoff[2], zemb + zoff[3], b.h2, n, hd, hd, 0, 1, s));
+  DRM_TRY(launch_linear(b.h2, zemb + zoff[4], zemb + zoff[5], b.temb, n, hd, mc, 0, 1, s));
+  // IllNet(cat[Lr_k, LrK], t_emb)             (models/drmnet.py:455-456, :54-61)
+  DRM_TRY(illnet->forward(Lr_k, 3, LrK, 3, rows, b.temb, nullptr, nullptr, b.eps, n, H, W, ar, s));
+  ar.release(net_mark);
+  const size_t total = (size_t)n * chw;
+  hipLaunchKernelGGL(drmnet_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Lr_k, b.eps, rows, b.conv, noise, n, chw,
+                     cfg.delta, seed, (uint64_t)(i + 1) * (uint64_t)B * chw);
+  DRM_HIP_CHECK(hipGetLastError());
+  if (zk_out) DRM_HIP_CHECK(hipMemcpyAsync(zk_out, b.zk, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (zK_out) DRM_HIP_CHECK(hipMemcpyAsync(zK_out, b.zKc, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (conv_out) DRM_HIP_CHECK(hipMemcpyAsync(conv_out, b.conv, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  last = b.conv;
+  last_zKc = b.zKc;
+  return DRM_OK;
+}
+
+int DrmnetSampler::sample(const float* LrK, const float* noise0, const float* step_noise, uint64_t seed, int early_exit, float* Lr0, float* zK,
+                          int32_t* K, int32_t* steps_done, int B, int H, int W, Arena& ar, hipStream_t s) {
+  const int zd = cfg.z_dim;
+  const size_t chw = (size_t)3 * H * W;
+  if (h_cap < B) {
+    if (h_rows) (void)hipHostFree(h_rows);
+    if (h_conv) (void)hipHostFree(h_conv);
+    DRM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_rows), (size_t)B * sizeof(int32_t)));
+    DRM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_conv), (size_t)B * sizeof(int32_t)));
+    h_cap = B;
+  }
+  int32_t* d_rows = ar.alloc<int32_t>((size_t)B);
+  if (ar.failed) { set_error("drmnet sample: workspace too small"); return DRM_ERR_WORKSPACE; }
+  const size_t mark = ar.mark();
+  const size_t total = (size_t)B * chw;
+  hipLaunchKernelGGL(drmnet_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, LrK, noise0, Lr0, total, cfg.delta, seed);
+  DRM_HIP_CHECK(hipGetLastError());
+  DRM_TRY(fill_f32(zK, (size_t)B * zd, NAN, s));
+  DRM_TRY(fill_i32(K, (size_t)B, cfg.max_timesteps, s));
+  std::vector<int32_t> active(B);
+  for (int b = 0; b < B; ++b) active[b] = b;
+  int steps = 0;
+  for (int i = 0; i < cfg.max_timesteps; ++i) {
+    const int n = (int)active.size();
+    for (int j = 0; j < n; ++j) h_rows[j] = active[j];
+    DRM_HIP_CHECK(hipMemcpyAsync(d_rows, h_rows, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    const float* nz = step_noise ? step_noise + (size_t)i * B * chw : nullptr;
+    ar.release(mark);
+    DRM_TRY(step(Lr0, LrK, d_rows, n, i, nz, seed, nullptr, nullptr, nullptr, B, H, W, ar, s));
+    ++steps;
+    if (early_exit) {
+      hipLaunchKernelGGL(drmnet_record_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_rows, last, last_zKc, n, zd, i, zK, K);
+      DRM_HIP_CHECK(hipGetLastError());
+      DRM_HIP_CHECK(hipMemcpyAsync(h_conv, last, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      DRM_HIP_CHECK(hipStreamSynchronize(s));  // the reference syncs here too (torch.any, models/drmnet.py:841)
+      std::vector<int32_t> next;
+      next.reserve(n);
+      for (int j = 0; j < n; ++j)
+        if (!h_conv[j]) next.push_back(active[j]);
+      active.swap(next);
+      if (active.empty()) break;
+    }
+  }
+  if (steps_done) *steps_done = steps;
+  return DRM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ DDIM / DDPM drivers
+
+size_t sampler_workspace_bytes(UNet* net, int N, int H, int W) {
+  Arena a;
+  a.dry = true;
+  if (net->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a, nullptr) != DRM_OK) return 0;
+  const size_t chw = (size_t)net->desc.out_channels * H * W;
+  return a.peak + ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + 512;
+}
+
+int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s) {
+  DRM_REQUIRE(net && net->desc.kind == 0, "ddim needs a UNetModel");
+  DRM_REQUIRE(S >= 1 && timesteps && coef, "ddim schedule");
+  const int Cx = net->desc.out_channels, Cc = net->desc.in_channels - Cx;
+  const size_t n = (size_t)N * Cx * H * W;
+  float* e = ar.alloc<float>(n);
+  float* tf = ar.alloc<float>((size_t)N);
+  if (ar.failed) { set_error("ddim: workspace too small"); return DRM_ERR_WORKSPACE; }
+  const size_t mark = ar.mark();
+  const int steps = (num_steps > 0 && num_steps < S) ? num_steps : S;
+  for (int j = 0; j < steps; ++j) {
+    const int index = S - 1 - j;
+    DRM_TRY(fill_f32(tf, N, (float)timesteps[index], s));
+    ar.release(mark);
+    DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
+    const float* c = coef + 5 * index;
+    hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, e, noise ? noise + (size_t)j * n : nullptr, n,
+                       c[0], c[1], c[2], c[3], c[4], seed, (uint64_t)(j + 1) * n);
+    DRM_HIP_CHECK(hipGetLastError());
+  }
+  return DRM_OK;
+}
+
+int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip, const float* noise,
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s) {
+  DRM_REQUIRE(net && net->desc.kind == 0, "ddpm needs a UNetModel");
+  DRM_REQUIRE(T_start >= 1 && coef, "ddpm schedule");
+  const int Cx = net->desc.out_channels, Cc = net->desc.in_channels - Cx;
+  const size_t n = (size_t)N * Cx * H * W;
+  float* e = ar.alloc<float>(n);
+  float* tf = ar.alloc<float>((size_t)N);
+  if (ar.failed) { set_error("ddpm: workspace too small"); return DRM_ERR_WORKSPACE; }
+  const size_t mark = ar.mark();
+  for (int j = 0; j < T_start; ++j) {
+    const int t = T_start - 1 - j;
+    DRM_TRY(fill_f32(tf, N, (float)t, s));
+    ar.release(mark);
+    DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
+    const float* c = coef + 5 * t;
+    hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, pred_x0, e,
+                       noise ? noise + (size_t)j * n : nullptr, n, c[0], c[1], c[2], c[3], c[4], t != 0 ? 1 : 0, clip, seed, (uint64_t)(j + 1) * n);
+    DRM_HIP_CHECK(hipGetLastError());
+  }
+  return DRM_OK;
+}
+
+}  // namespace drm

@@ -1,0 +1,268 @@
+"""Host-side mirror of the reference U-Net modules, backed by the HIP engine.
+
+Drop-in for ``ldm.modules.diffusionmodules.openaimodel.UNetModel`` /
+``EncoderUNetModel`` (reference openaimodel.py:422-768, :771-991): same constructor
+parameters, same ``state_dict()`` keys/shapes/order (so reference checkpoints and EMA
+buffers load unchanged), same ``forward`` signatures.  The modules hold only
+``nn.Parameter`` storage; all arithmetic runs in libdrmnet_hip.so on the tensors'
+device.  There is no PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_ZERO_INIT_SUFFIXES = (".out_layers.3.weight", ".out_layers.3.bias", ".proj_out.weight", ".proj_out.bias")
+
+
+def _reject_unsupported(kind: str, **kw) -> None:
+    """Only the configuration space the shipped YAMLs use is implemented."""
+    bad = []
+    if kw.get("use_spatial_transformer"):
+        bad.append("use_spatial_transformer=True")
+    if kw.get("context_dim") is not None:
+        bad.append("context_dim")
+    if kw.get("resblock_updown"):
+        bad.append("resblock_updown=True")
+    if kw.get("conv_resample", True):
+        bad.append("conv_resample=True (the shipped configs set False)")
+    if kw.get("use_scale_shift_norm"):
+        bad.append("use_scale_shift_norm=True")
+    if kw.get("dims", 2) != 2:
+        bad.append("dims != 2")
+    if kw.get("use_fp16"):
+        bad.append("use_fp16=True")
+    if kw.get("num_classes") is not None:
+        bad.append("num_classes")
+    if kw.get("num_heads", 1) not in (1,) or kw.get("num_head_channels", -1) != -1:
+        bad.append("num_heads != 1 / num_head_channels")
+    if kw.get("num_heads_upsample", -1) not in (-1, 1):
+        bad.append("num_heads_upsample")
+    if kw.get("use_new_attention_order"):
+        bad.append("use_new_attention_order=True")
+    if kw.get("use_positional_embedded_attention"):
+        bad.append("use_positional_embedded_attention=True")
+    if kw.get("n_embed") is not None:
+        bad.append("n_embed")
+    if kw.get("dropout", 0) not in (0, 0.0):
+        bad.append("dropout != 0 (inference only)")
+    if kind == "encoder" and kw.get("pool", "adaptive") != "adaptive":
+        bad.append("pool != 'adaptive'")
+    if bad:
+        raise NotImplementedError(f"drmnet_amd {kind}: unsupported parameters: " + ", ".join(bad))
+
+
+class _Holder(nn.Module):
+    """Pure parameter container; never called."""
+
+
+def _attach(root: nn.Module, key: str, param: nn.Parameter) -> None:
+    parts = key.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Holder())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], param)
+
+
+class _HipUNetBase(nn.Module):
+    _kind = 0
+
+    def _setup(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, channel_mult):
+        self.in_channels = int(in_channels)
+        self.model_channels = int(model_channels)
+        self.out_channels = int(out_channels)
+        self.num_res_blocks = int(num_res_blocks)
+        self.attention_resolutions = [int(a) for a in attention_resolutions]
+        self.channel_mult = [int(m) for m in channel_mult]
+        self.dtype = torch.float32
+        d = _lib.UNetDesc()
+        d.kind = self._kind
+        d.in_channels, d.model_channels, d.out_channels = self.in_channels, self.model_channels, self.out_channels
+        d.num_res_blocks = self.num_res_blocks
+        if len(self.channel_mult) > _lib.MAX_LEVELS or len(self.attention_resolutions) > _lib.MAX_LEVELS:
+            raise NotImplementedError("more than 8 levels")
+        d.n_levels = len(self.channel_mult)
+        for i, m in enumerate(self.channel_mult):
+            d.channel_mult[i] = m
+        d.n_attn = len(self.attention_resolutions)
+        for i, a in enumerate(self.attention_resolutions):
+            d.attention_resolutions[i] = a
+        L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(L.drm_unet_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self._ws = _lib.Workspace()
+        self._loaded_sig = None
+        # parameter table straight from the engine == reference state_dict() order
+        n = L.drm_unet_param_count(h)
+        self._keys: List[str] = []
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        for i in range(n):
+            _lib.check(L.drm_unet_param_info(h, i, name, 256, shape, C.byref(nd)))
+            key = name.value.decode()
+            shp = tuple(int(shape[k]) for k in range(nd.value))
+            _attach(self, key, nn.Parameter(self._init_tensor(key, shp), requires_grad=False))
+            self._keys.append(key)
+
+    @staticmethod
+    def _init_tensor(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
+        if key.endswith(_ZERO_INIT_SUFFIXES) or key.startswith(("out.2.", "out.3.")):
+            return torch.zeros(shape)  # zero_module(...) in the reference (openaimodel.py:229-231,314,706,927)
+        if len(shape) >= 2:
+            bound = 1.0 / math.sqrt(max(1, int(torch.tensor(shape[1:]).prod())))
+            return torch.empty(shape).uniform_(-bound, bound)
+        return torch.ones(shape) if key.endswith("weight") else torch.zeros(shape)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().drm_unet_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------ weights
+    def param_tensors(self) -> List[torch.Tensor]:
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in self._keys]
+
+    def sync_weights(self, force: bool = False) -> None:
+        """(Re)upload parameters to the engine when they changed (load_state_dict, ema_scope swap, .to(device))."""
+        ps = self.param_tensors()
+        sig = tuple((p.data_ptr(), p._version) for p in ps)
+        if not force and sig == self._loaded_sig:
+            return
+        dev = ps[0].device
+        for k, p in zip(self._keys, ps):
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                raise RuntimeError(f"parameter {k} must be a contiguous fp32 tensor on one GPU (got {p.device}, {p.dtype}); call .cuda() first")
+        arr = _lib.ptr_array(ps)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().drm_unet_load_params(self._h, arr, len(ps), _lib.stream_ptr(dev)))
+        self._loaded_sig = sig
+
+    def engine_handle(self):
+        self.sync_weights()
+        return self._h
+
+    def workspace_bytes(self, n: int, h: int, w: int) -> int:
+        return int(_lib.lib().drm_unet_workspace_bytes(self._h, n, h, w))
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def _run(self, x, cond, t_emb, timesteps, rows=None):
+        x = _lib.require_gpu_tensor(x, "x")
+        dev = x.device
+        n = x.shape[0] if rows is None else rows.shape[0]
+        cx, hh, ww = x.shape[1], x.shape[2], x.shape[3]
+        cc = 0
+        if cond is not None:
+            cond = _lib.require_gpu_tensor(cond, "cond")
+            cc = cond.shape[1]
+            if cond.shape[0] != x.shape[0] or cond.shape[2:] != x.shape[2:]:
+                raise RuntimeError("x / cond shape mismatch")
+        if cx + cc != self.in_channels:
+            raise RuntimeError(f"expected {self.in_channels} input channels, got {cx}+{cc}")
+        tf = None
+        ti = None
+        if timesteps is not None:
+            if timesteps.dtype == torch.int64:
+                ti = _lib.require_gpu_tensor(timesteps, "timesteps", torch.int64)
+            else:
+                tf = _lib.require_gpu_tensor(timesteps.float(), "timesteps")
+        if t_emb is not None:
+            t_emb = _lib.require_gpu_tensor(t_emb, "t_emb")
+            if tuple(t_emb.shape) != (n, self.model_channels):
+                raise RuntimeError(f"t_emb must be [{n}, {self.model_channels}]")
+        if rows is not None:
+            rows = _lib.require_gpu_tensor(rows, "rows", torch.int32)
+        self.sync_weights()
+        L = _lib.lib()
+        need = int(L.drm_unet_workspace_bytes(self._h, n, hh, ww))
+        ws = self._ws.get(need, dev)
+        if self._kind == 0:
+            out = torch.empty((n, self.out_channels, hh, ww), dtype=torch.float32, device=dev)
+        else:
+            out = torch.empty((n, self.out_channels), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(
+                L.drm_unet_forward(self._h, x.data_ptr(), cx, _lib.ptr(cond), cc, _lib.ptr(rows), _lib.ptr(t_emb), _lib.ptr(ti), _lib.ptr(tf),
+                                   out.data_ptr(), n, hh, ww, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+            )
+        return out
+
+
+class UNetModel(_HipUNetBase):
+    """``UNetModel(image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, ...)``
+    -- reference openaimodel.py:452-478 (same parameter names and defaults)."""
+
+    _kind = 0
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=-1,
+                 num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True,
+                 use_positional_embedded_attention=False):
+        super().__init__()
+        if num_heads == -1:
+            assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+        _reject_unsupported("UNetModel", dropout=dropout, conv_resample=conv_resample, dims=dims, num_classes=num_classes, use_fp16=use_fp16,
+                            num_heads=num_heads, num_head_channels=num_head_channels, num_heads_upsample=num_heads_upsample,
+                            use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
+                            use_new_attention_order=use_new_attention_order, use_spatial_transformer=use_spatial_transformer,
+                            context_dim=context_dim, n_embed=n_embed, use_positional_embedded_attention=use_positional_embedded_attention)
+        self.image_size = image_size
+        self.num_classes = None
+        self._setup(in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, channel_mult)
+
+    def forward(self, x, timesteps=None, context=None, y=None, t_emb=None, **kwargs):
+        """openaimodel.py:731-768. ``x`` is the already-concatenated [N, in_channels, H, W] tensor."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        if (timesteps is None) == (t_emb is None):
+            raise ValueError("timesteps and t_emb cannot be specified at the same time")
+        if context is not None:
+            raise NotImplementedError("cross-attention context (use_spatial_transformer) is not supported")
+        return self._run(x, None, t_emb, timesteps)
+
+    def forward_parts(self, x, cond, timesteps=None, t_emb=None, rows=None):
+        """Same as forward(cat([x, cond], 1), ...) without materialising the concat; ``rows`` gathers samples."""
+        if (timesteps is None) == (t_emb is None):
+            raise ValueError("timesteps and t_emb cannot be specified at the same time")
+        return self._run(x, cond, t_emb, timesteps, rows)
+
+
+class EncoderUNetModel(_HipUNetBase):
+    """Reference openaimodel.py:777-802 (same parameter names and defaults)."""
+
+    _kind = 1
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, use_checkpoint=False, use_fp16=False, num_heads=1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False, pool="adaptive",
+                 use_positional_embedded_attention=False, *args, **kwargs):
+        super().__init__()
+        _reject_unsupported("encoder", dropout=dropout, conv_resample=conv_resample, dims=dims, use_fp16=use_fp16, num_heads=num_heads,
+                            num_head_channels=num_head_channels, num_heads_upsample=num_heads_upsample, use_scale_shift_norm=use_scale_shift_norm,
+                            resblock_updown=resblock_updown, use_new_attention_order=use_new_attention_order, pool=pool,
+                            use_positional_embedded_attention=use_positional_embedded_attention)
+        self.image_size = image_size
+        self.pool = pool
+        self._setup(in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, channel_mult)
+
+    def forward(self, x, timesteps):
+        """openaimodel.py:969-991 -> [N, out_channels]."""
+        return self._run(x, None, None, timesteps)
+
+    def forward_parts(self, x, cond, timesteps, rows=None):
+        return self._run(x, cond, None, timesteps, rows)

@@ -1,0 +1,157 @@
+/* drmnet_hip.h -- C ABI of the MI355X-native DRMNet reverse-diffusion hot path.
+ *
+ * One shared library (drmnet_amd/csrc/libdrmnet_hip.so), plain pointers and sizes, no torch types.
+ * All tensor memory is BORROWED from the caller (device pointers, fp32, contiguous); the library owns
+ * only the packed-weight storage behind its handles.  Every entry point takes an explicit hipStream_t
+ * (passed as void*), launches asynchronously and never synchronises, except the documented per-step
+ * convergence read-back inside drm_drmnet_sample.  Return value 0 = OK, non-zero = error code with the
+ * text available from drm_last_error(); nothing throws across the ABI.
+ *
+ * The reference (kyotovision-public/DRMNet) is 100 % Python with no FFI of its own, so each entry point
+ * names the reference Python interface it replaces (paths relative to the reference root).
+ */
+#ifndef DRMNET_HIP_H
+#define DRMNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRM_ABI_VERSION 1
+#define DRM_MAX_LEVELS 8
+
+int drm_abi_version(void);
+const char* drm_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * U-Net family.  Replaces ldm/modules/diffusionmodules/openaimodel.py:
+ *   UNetModel.__init__/forward        :452-713 / :731-768   (kind 0; IllNet and ObsNet)
+ *   EncoderUNetModel.__init__/forward :777-953 / :969-991   (kind 1; RefNet, pool="adaptive")
+ * Only the configuration space the shipped YAMLs use is accepted (num_heads=1, conv_resample=False,
+ * resblock_updown=False, use_scale_shift_norm=False, dims=2, fp32); anything else is rejected.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct drm_unet_desc {
+  int32_t kind;           /* 0 = UNetModel, 1 = EncoderUNetModel */
+  int32_t in_channels;    /* channels of cat([x, cond], 1); 6 in every shipped config */
+  int32_t model_channels;
+  int32_t out_channels;
+  int32_t num_res_blocks;
+  int32_t n_levels;
+  int32_t channel_mult[DRM_MAX_LEVELS];
+  int32_t n_attn;
+  int32_t attention_resolutions[DRM_MAX_LEVELS];
+} drm_unet_desc;
+
+typedef struct drm_unet drm_unet;
+
+/* Builds the block topology and the parameter table (host only, no GPU needed). */
+int drm_unet_create(const drm_unet_desc* desc, drm_unet** out);
+void drm_unet_destroy(drm_unet* net);
+
+/* Parameter table == the reference module's state_dict() order, names and shapes
+ * (e.g. "input_blocks.1.0.in_layers.2.weight", [128,128,3,3]). */
+int drm_unet_param_count(const drm_unet* net);
+int drm_unet_param_info(const drm_unet* net, int index, char* name, int name_cap, int64_t shape[4], int* ndim);
+
+/* Uploads/repacks all parameters. ptrs[i] = device pointer to fp32 tensor i in PyTorch layout.
+ * Replaces nn.Module.load_state_dict + LitEma.copy_to (ldm/modules/ema.py:46-53): the host passes the
+ * EMA tensors when sampling under ema_scope. May be called again to swap weights. */
+int drm_unet_load_params(drm_unet* net, const float* const* ptrs, int count, void* stream);
+
+/* Workspace (activations, statistics, attention scores) needed by one forward of batch N at HxW. */
+size_t drm_unet_workspace_bytes(const drm_unet* net, int N, int H, int W);
+
+/* kind 0: UNetModel.forward(cat([x, cond],1), timesteps=t | t_emb=t_emb) -> out [N,out_channels,H,W] NCHW.
+ * kind 1: EncoderUNetModel.forward(cat([x, cond],1), timesteps)           -> out [N,out_channels].
+ *   x    : [*, Cx, H, W] NCHW,  cond: [*, Cc, H, W] NCHW (Cx + Cc == in_channels; cond may be NULL if Cc == 0)
+ *   rows : optional int32[N] gather indices into x/cond (DRMNet active-set compaction,
+ *          models/drmnet.py:810-813); NULL = identity.
+ *   t_emb: [N, model_channels] or NULL;  timesteps: int64[N] or NULL;  timesteps_f: fp32[N] or NULL
+ *          (exactly one of the three; kind 1 needs timesteps / timesteps_f). */
+int drm_unet_forward(drm_unet* net, const float* x, int Cx, const float* cond, int Cc, const int32_t* rows, const float* t_emb,
+                     const int64_t* timesteps, const float* timesteps_f, float* out, int N, int H, int W, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Primitive ops on reference-layout tensors (NCHW activations, PyTorch weights).  They allocate their
+ * own scratch and are meant for parity tests / per-module drop-ins, not for the timed path.
+ * ------------------------------------------------------------------------------------------- */
+/* nn.Linear with optional SiLU before/after: out[N,O] = act(b + act(in[N,I]) W[O,I]^T)
+ * (time_embed, emb_layers: openaimodel.py:521-526,218-224; z_emb_layer: models/drmnet.py:38-45) */
+int drm_linear_forward(const float* in, const float* w, const float* b, float* out, int N, int I, int O, int silu_in, int silu_out, void* stream);
+/* timestep_embedding(timesteps, dim) (ldm/modules/diffusionmodules/util.py:151-171) */
+int drm_timestep_embedding(const int64_t* timesteps, float* out, int N, int dim, void* stream);
+/* [GroupNorm32 -> [SiLU] ->] conv2d k x k (k in {1,3}, stride 1, pad k/2) [+ emb[n,co]] [+ residual]
+ * (ResBlock.in_layers / out_layers / skip_connection: openaimodel.py:201-241). gamma/beta NULL = no norm. */
+int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, int silu, const float* w, const float* b, int ksize,
+                         const float* emb, const float* residual, float* out, int N, int Cin, int Cout, int H, int W, void* stream);
+/* ResBlock._forward (openaimodel.py:255-275) on cat([x0 (optionally nearest-x2 upsampled), x1], 1).
+ * params: 10 (or 12 with skip_connection) pointers in state_dict order. emb: [N, emb_dim]. */
+int drm_op_resblock(const float* x0, int C0, int up0, const float* x1, int C1, const float* emb, int emb_dim, const float* const* params,
+                    int n_params, float* out, int N, int Cout, int H, int W, void* stream);
+/* AttentionBlock._forward (openaimodel.py:325-333, QKVAttentionLegacy :365-381), params: norm.w, norm.b, qkv.w, qkv.b, proj.w, proj.b */
+int drm_op_attention_block(const float* x, const float* const* params, float* out, int N, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Samplers.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct drm_drmnet_cfg {
+  int32_t z_dim;          /* len(z0), 6 in the shipped config */
+  int32_t max_timesteps;
+  double gamma;           /* double: the reference evaluates gamma^i = exp(i ln gamma) in fp64 (models/drmnet.py:494-495) */
+  float epsilon, delta;   /* compared / multiplied in fp32 like the reference's tensor-scalar ops */
+  float z0[8];            /* mirror-reflectance code (configs/drmnet/eval_drmnet.yaml: z0) */
+} drm_drmnet_cfg;
+
+typedef struct drm_drmnet drm_drmnet;
+
+/* DRMNet reverse process over (RefNet, IllNet, z_emb_layer). Borrows the two nets (caller keeps them alive).
+ * zemb: 6 device pointers = ZEmbDiffusionWrapper.z_emb_layer.{0,2,4}.{weight,bias} (models/drmnet.py:38-45). */
+int drm_drmnet_create(drm_unet* illnet, drm_unet* refnet, const float* const* zemb, const drm_drmnet_cfg* cfg, drm_drmnet** out);
+void drm_drmnet_destroy(drm_drmnet* s);
+size_t drm_drmnet_workspace_bytes(const drm_drmnet* s, int N, int H, int W);
+
+/* One reverse step on the active rows (DRMNet.p_mean_variance + the loop body, models/drmnet.py:752-770,809-839):
+ *   z_out = RefNet(cat[Lr_k, LrK], i); zk = clamp(z0 + gamma^i (z_out - z0)); out = IllNet(cat[Lr_k, LrK], z_emb(zk - z0));
+ *   Lr_k[rows] += out (+ delta * noise on rows that did not converge).
+ * Lr_k, LrK: [B,3,H,W]; rows: int32[n_active] (device); noise: [B,3,H,W] or NULL (then Philox(seed, step));
+ * zk_out / zK_out: [n_active, z_dim]; converged_out: int32[n_active] (device). */
+int drm_drmnet_step(drm_drmnet* s, float* Lr_k, const float* LrK, const int32_t* rows, int n_active, int step, const float* noise,
+                    uint64_t seed, float* zk_out, float* zK_out, int32_t* converged_out, int B, int H, int W, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* DRMNet.p_sample_loop (models/drmnet.py:782-847): LrK [B,3,H,W] -> Lr0 [B,3,H,W], zK [B,z_dim] (NaN if never
+ * converged), K int32[B].  noise0 [B,3,H,W] / step_noise [max_timesteps,B,3,H,W] or NULL (Philox).
+ * early_exit = 0 keeps every row active for max_timesteps steps (countable-steps benchmark mode).
+ * Synchronises the stream once per step to read the convergence flags (the reference does the same,
+ * models/drmnet.py:841).  steps_done returns the number of executed steps. */
+int drm_drmnet_sample(drm_drmnet* s, const float* LrK, const float* noise0, const float* step_noise, uint64_t seed, int early_exit,
+                      float* Lr0, float* zK, int32_t* K, int32_t* steps_done, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* DDIM sampling (DDIMSampler.ddim_sampling + p_sample_ddim, ldm/models/diffusion/ddim.py:128-259).
+ *   timesteps: int64[S] (host) ddim_timesteps; coef: float[S][5] (host) = sqrt(a_t), sqrt(1-a_t), sqrt(a_prev),
+ *   sqrt(1-a_prev-sigma^2), sigma per index; runs index S-1 .. 0 (or the first num_steps of them).
+ *   x: [N,3,H,W] in = x_T, out = final x;  cond: [N,3,H,W];  noise: [steps,N,3,H,W] or NULL (Philox). */
+int drm_ddim_sample(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
+                    const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Ancestral DDPM (LatentDiffusion.p_sample via ObsNetDiffusion.p_sample_loop, ldm/models/diffusion/ddpm.py:1079-1167,
+ * models/obsnet.py:500-564).  coef: float[T][5] (host) = sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+ * posterior_mean_coef1, posterior_mean_coef2, exp(0.5*posterior_log_variance_clipped) for t = 0..T-1; runs t = T_start-1 .. 0.
+ * x: in = x_T, out = last img; pred_x0: [N,3,H,W] out (what ObsNetDiffusion.p_sample_loop returns). */
+int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
+                    const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
+size_t drm_sampler_workspace_bytes(const drm_unet* net, int N, int H, int W);
+
+/* Standard-normal fill from the library's Philox4x32-10 stream (throughput mode noise source). */
+int drm_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRMNET_HIP_H */
