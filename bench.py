@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Headline benchmark: U-Net denoise steps/sec of DRMNet's reverse process on synthetic 3x128x256 refmaps.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: a full DRMNet reverse step for `--batch` refmaps per GPU
+(RefNet forward -> BRDF schedule -> z-embedding MLP -> IllNet forward -> fused state update, models/drmnet.py:809-825 of
+the reference), all rows active, fp32, inputs resident in HBM.  value = sample-steps/s summed over all GPUs (weak scaling:
+every rank owns its own `--batch` refmaps; the path has no collective -- samples are independent).
+
+The JSON line carries
+  roofline     : dominant kernel = fused GroupNorm+SiLU+conv3x3 implicit GEMM (conv.hip); achieved = algorithmic conv3x3
+                 FLOPs of its launches / their summed duration, both measured with HIP events on the launch stream inside the
+                 timed region (library profiler, include/drmnet_hip.h drm_profile_*); peak = 157.3 TFLOP/s fp32 MFMA.
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference's arithmetic) timed on this box's host cores on a bounded
+                 sample of the same workload (rank 0, N = 1 only).
+Other workloads (--workload illnet | refnet | obsnet | obsnet_ddim) time a single network / sampler for the DESIGN.md tables.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+# algorithmic matmul GFLOP per sample per forward (measured from the reference modules)
+GFLOP = {"illnet": {(128, 128): 202.66, (128, 256): 406.76}, "refnet": {(128, 128): 34.83, (128, 256): 70.10},
+         "obsnet": {(128, 128): 215.34, (128, 256): 448.24}}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="refmaps per GPU (BASELINE config[1]: 32)")
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def build_models(workload, dev):
+    from drmnet_amd import synth
+    from drmnet_amd.config import instantiate_from_config, load_config
+
+    if workload in ("drmnet_step", "illnet", "refnet"):
+        cfg = load_config(os.path.join(ROOT, "configs/drmnet/eval_drmnet.yaml"))["model"]
+        cfg["params"].pop("ckpt_path")
+        cfg["params"]["use_ema"] = False  # no checkpoint offline: EMA == live weights, skip the second copy
+        m = instantiate_from_config(cfg)
+        synth.load_synth(m.illnet_model.diffusion_model, synth.SEED_ILLNET)
+        synth.load_synth(m.refnet_model.diffusion_model, synth.SEED_REFNET)
+        m.illnet_model.z_emb_layer.load_state_dict(synth.synth_state_dict(
+            [(k, tuple(v.shape)) for k, v in m.illnet_model.z_emb_layer.state_dict().items()], synth.SEED_ZEMB))
+        return m.to(dev)
+    cfg = load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["model"]
+    cfg["params"].pop("ckpt_path")
+    cfg["params"]["use_ema"] = False
+    m = instantiate_from_config(cfg)
+    synth.load_synth(m.model.diffusion_model, synth.SEED_OBSNET)
+    return m.to(dev)
+
+
+def make_step(args, model, dev):
+    """Returns (callable running ONE step on the current stream, algorithmic GFLOP per sample-step, description)."""
+    from drmnet_amd import _lib, synth
+
+    B, H, W = args.batch, args.height, args.width
+    x = synth.synth_refmaps(B, H, W, synth.SEED_INPUT).to(dev)
+    L = _lib.lib()
+    key = (H, W)
+    if args.workload == "drmnet_step":
+        h = model._engine()
+        ws = model._ws.get(int(L.drm_drmnet_workspace_bytes(h, B, H, W)), dev)
+        Lr_k = x.clone()
+        state = {"i": 0}
+
+        def step():
+            i = state["i"] % model.max_timesteps
+            _lib.check(L.drm_drmnet_step(h, Lr_k.data_ptr(), x.data_ptr(), None, B, i, None, 1234, None, None, None, B, H, W,
+                                         ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+            state["i"] += 1
+
+        gf = GFLOP["illnet"].get(key, 0) + GFLOP["refnet"].get(key, 0)
+        return step, gf, "DRMNet reverse step = RefNet + z-MLP + IllNet + update (all rows active)"
+    if args.workload in ("illnet", "refnet", "obsnet"):
+        unet = {"illnet": lambda: model.illnet_model.diffusion_model, "refnet": lambda: model.refnet_model.diffusion_model,
+                "obsnet": lambda: model.model.diffusion_model}[args.workload]()
+        gen = torch.Generator().manual_seed(5)
+        t_emb = torch.randn((B, 128), generator=gen).to(dev)
+        t = torch.full((B,), 500, dtype=torch.long, device=dev)
+        xk = (x + 0.025 * torch.randn(x.shape, generator=gen).to(dev)).contiguous()
+
+        def step():
+            if args.workload == "illnet":
+                unet.forward_parts(xk, x, t_emb=t_emb)
+            elif args.workload == "refnet":
+                unet.forward_parts(xk, x, t)
+            else:
+                unet.forward_parts(xk, x, timesteps=t)
+
+        return step, GFLOP[args.workload].get(key, 0), f"{args.workload} U-Net forward"
+    # obsnet_ddim: one DDIM step (U-Net + fused update, Philox noise)
+    from drmnet_amd.ddim import DDIMSampler
+
+    s = DDIMSampler(model)
+    s.make_schedule(50, ddim_eta=1.0, verbose=False)
+    xT = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+
+    def step():
+        s.ddim_sampling(x, tuple(x.shape), x_T=xT, num_steps=1, seed=1)
+
+    return step, GFLOP["obsnet"].get(key, 0), "ObsNet DDIM step (eta=1)"
+
+
+def cpu_baseline(args):
+    """Oracle (CPU port of the reference arithmetic) on a bounded sample: batch 1 of the same shape, a few steps."""
+    from drmnet_amd import synth
+    from oracle import samplers as osamp
+    from oracle import unet as ou
+
+    H, W = args.height, args.width
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    Pi = synth.synth_state_dict(ou.param_manifest(ou.ILLNET_CFG, "unet"), synth.SEED_ILLNET)
+    Pr = synth.synth_state_dict(ou.param_manifest(ou.REFNET_CFG, "encoder"), synth.SEED_REFNET)
+    Pz = synth.synth_state_dict(ou.zemb_manifest(6, 128), synth.SEED_ZEMB)
+    ti, tr = ou.build_topology(ou.ILLNET_CFG, "unet"), ou.build_topology(ou.REFNET_CFG, "encoder")
+    x = synth.synth_refmaps(1, H, W, synth.SEED_INPUT)
+    z0 = torch.tensor([1.0, 1, 1, 1, 0, 1])
+    Lr = x.clone()
+
+    def one(i):
+        xc = torch.cat([Lr, x], 1)
+        z = ou.encoder_forward(Pr, tr, xc, torch.full((1,), i, dtype=torch.long))
+        zk, _ = osamp.brdf_schedule(z, z0, 0.95, i)
+        return Lr + ou.unet_forward(Pi, ti, xc, t_emb=ou.z_embed(Pz, zk - z0))
+
+    one(0)  # warm-up
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < 10.0 and n < 12):
+        one(n)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n / dt, 4), "unit": "U-Net denoise steps/sec", "cores": threads, "kind": "port",
+            "sample": f"{n} DRMNet reverse steps (RefNet+IllNet, fp32) of 1 refmap 3x{H}x{W}, oracle/ on host CPU, {dt:.1f}s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: drmnet_amd has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from drmnet_amd import _lib
+
+    L = _lib.lib()
+    model = build_models(args.workload, dev)
+    step, gflop, desc = make_step(args, model, dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    profile = not args.no_profile
+    if profile:
+        L.drm_profile_reset()
+        L.drm_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if profile:
+        L.drm_profile_enable(0)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    breakdown = None
+    if profile:
+        K = 5
+        ms, fl, by, n = (C.c_double * K)(), (C.c_double * K)(), (C.c_double * K)(), (C.c_int64 * K)()
+        _lib.check(L.drm_profile_collect(ms, fl, by, n))
+        names = ["conv3x3_gn_silu_igemm", "conv1x1_igemm", "attention_core", "gn_channel_moments", "other"]
+        breakdown = {names[k]: {"ms": round(ms[k], 3), "launches": int(n[k]), "tflops": round(fl[k] / ms[k] / 1e9, 2) if ms[k] > 0 else None,
+                                "algorithmic_GBps": round(by[k] / ms[k] / 1e6, 1) if ms[k] > 0 else None} for k in range(K) if n[k] > 0}
+        if n[0] > 0:
+            ach = fl[0] / (ms[0] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp32 v_mfma_f32_32x32x2_f32)",
+                        "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "launches": int(n[0]), "avg_launch_ms": round(ms[0] / n[0], 4),
+                        "flops_per_launch": round(fl[0] / n[0], 1), "share_of_step_time": round(ms[0] * 1e-3 / dt, 3)}
+
+    if rank == 0:
+        total_steps = args.batch * world * args.steps
+        value = total_steps / dt
+        out = {
+            "metric": "U-Net denoise steps/sec on 3x128x256 refmaps",
+            "value": round(value, 3),
+            "unit": "denoise steps/sec (samples x steps / s)",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": args.batch, "refmap": f"3x{args.height}x{args.width}",
+                       "weights": "seeded synthetic (no checkpoint offline)", "parallelism": f"batch-sharded x{world}, no collective",
+                       "algorithmic_gflop_per_sample_step": gflop, "achieved_tflops_per_gpu": round(value / world * gflop / 1e3, 2)},
+            "roofline": roofline,
+            "kernel_breakdown": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "drmnet_step":
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,7 @@ SYMBOLS = [
     "drm_linear_forward", "drm_timestep_embedding", "drm_op_norm_act_conv", "drm_op_resblock", "drm_op_attention_block",
     "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_step", "drm_drmnet_sample",
     "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddpm_sample", "drm_randn",
+    "drm_profile_enable", "drm_profile_reset", "drm_profile_collect",
 ]
 
 
@@ -78,12 +79,16 @@ def lib() -> C.CDLL:
     L.drm_drmnet_workspace_bytes.argtypes = [vp, i32, i32, i32]
     L.drm_drmnet_workspace_bytes.restype = C.c_size_t
     L.drm_drmnet_step.argtypes = [vp, fp, fp, vp, i32, i32, fp, C.c_uint64, fp, fp, vp, i32, i32, i32, vp, C.c_size_t, vp]
-    L.drm_drmnet_sample.argtypes = [vp, fp, fp, fp, C.c_uint64, i32, fp, fp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_drmnet_sample.argtypes = [vp, fp, fp, fp, fp, C.c_uint64, i32, fp, fp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_sampler_workspace_bytes.argtypes = [vp, i32, i32, i32]
     L.drm_sampler_workspace_bytes.restype = C.c_size_t
     L.drm_ddim_sample.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_ddpm_sample.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_randn.argtypes = [fp, C.c_size_t, C.c_uint64, C.c_uint64, vp]
+    L.drm_profile_enable.argtypes = [i32]
+    L.drm_profile_enable.restype = None
+    L.drm_profile_reset.restype = None
+    L.drm_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if L.drm_abi_version() != 1:
         raise RuntimeError("libdrmnet_hip.so ABI version mismatch")
     _lib = L

@@ -2,6 +2,7 @@
 #include <cstring>
 #include <memory>
 
+#include "profiler.h"
 #include "samplers.h"
 
 using namespace drm;
@@ -318,14 +319,14 @@ int drm_drmnet_step(drm_drmnet* s, float* Lr_k, const float* LrK, const int32_t*
   });
 }
 
-int drm_drmnet_sample(drm_drmnet* s, const float* LrK, const float* noise0, const float* step_noise, uint64_t seed, int early_exit,
+int drm_drmnet_sample(drm_drmnet* s, const float* LrK, const float* cond, const float* noise0, const float* step_noise, uint64_t seed, int early_exit,
                       float* Lr0, float* zK, int32_t* K, int32_t* steps_done, int B, int H, int W, void* workspace, size_t workspace_bytes,
                       void* stream) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(s && LrK && Lr0 && zK && K, "null argument");
+    DRM_REQUIRE(s && LrK && cond && Lr0 && zK && K, "null argument");
     Arena ar;
     DRM_TRY(make_arena(ar, workspace, workspace_bytes, s->s.workspace_bytes(B, H, W)));
-    return s->s.sample(LrK, noise0, step_noise, seed, early_exit, Lr0, zK, K, steps_done, B, H, W, ar, static_cast<hipStream_t>(stream));
+    return s->s.sample(LrK, cond, noise0, step_noise, seed, early_exit, Lr0, zK, K, steps_done, B, H, W, ar, static_cast<hipStream_t>(stream));
   });
 }
 
@@ -356,6 +357,16 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
     Arena ar;
     DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
     return ddpm_sample(&net->net, x, pred_x0, cond, coef, T_start, clip_denoised, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream));
+  });
+}
+
+void drm_profile_enable(int on) { prof_enable(on); }
+void drm_profile_reset(void) { prof_reset(); }
+int drm_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(ms && flops && bytes && launches, "null argument");
+    prof_collect(ms, flops, bytes, launches);
+    return DRM_OK;
   });
 }
 

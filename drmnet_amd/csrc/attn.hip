@@ -7,6 +7,7 @@
 // (SURVEY.md 8a), so the fused flash-style kernel is a later-round item; the GroupNorm, qkv and proj_out
 // projections and the residual add run in conv.hip (taps = 1).
 #include "common.h"
+#include "profiler.h"
 
 namespace drm {
 
@@ -139,6 +140,7 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
   DRM_REQUIRE(C % 4 == 0 && T > 0 && N > 0, "attention shape");
   const float alpha = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, applied once to the dot product
   const int tb = (T + 63) / 64;
+  ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C + 4.0 * T * T), s);
   hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
                      (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha);
   DRM_HIP_CHECK(hipGetLastError());

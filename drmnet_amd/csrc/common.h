@@ -64,6 +64,7 @@ struct ConvArgs {
   const float* res = nullptr;       // optional residual NHWC [N,H,W,Cout]; may alias out
   float* out = nullptr;             // NHWC [N,H,W,Cout], or NCHW [N,cout_valid,H,W] if out_nchw
   int out_nchw = 0, cout_valid = 0;
+  int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 // repack PyTorch conv weight [Cout][Cin][kh][kw] -> [taps][CinP/4][CoutP][4] (zero padded)

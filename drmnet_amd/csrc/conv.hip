@@ -17,6 +17,7 @@
 // Math: v_mfma_f32_32x32x2_f32 (exact fp32, 256 FLOP/clk/CU); each wave holds MT x NT 32x32 accumulators.
 // K order inside a chunk is permuted (lane half h takes k-groups 2j+h) so one b128 read feeds 4 MFMAs.
 #include "common.h"
+#include "profiler.h"
 
 namespace drm {
 
@@ -264,7 +265,15 @@ static int launch_variant(const ConvArgs& a, hipStream_t s) {
   const int groups = (a.N + C::TN - 1) / C::TN;
   const long long blocks = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
   DRM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid size");
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
+  {
+    // algorithmic work: 2 FLOP per MAC on un-padded channels; bytes = input read once + output written once + weights once
+    const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
+    const double px = (double)a.N * a.H * a.W;
+    const double px_in = (double)a.N * ((a.H >> a.up0) * (a.W >> a.up0)) * a.C0 + px * a.C1;
+    ProfScope ps(TAPS == 9 ? PROF_CONV3 : PROF_CONV1, 2.0 * px * TAPS * cin * cout,
+                 4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
+  }
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }

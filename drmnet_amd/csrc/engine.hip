@@ -354,7 +354,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   if (!c.dry()) {
     ConvArgs a;
     a.src0 = xin.p; a.C0 = in_cp; a.N = N; a.H = H; a.W = W;
-    a.w = Wb + stem_w; a.bias = Wb + stem_b; a.taps = 9; a.Cout = mc; a.out = h->p;
+    a.w = Wb + stem_w; a.bias = Wb + stem_b; a.taps = 9; a.Cout = mc; a.out = h->p; a.cin_real = desc.in_channels;
     DRM_TRY(launch_conv(a, s));
   }
   hs.push_back(h);

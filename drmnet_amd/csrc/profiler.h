@@ -1,0 +1,27 @@
+// Optional in-library launch profiler: HIP events recorded on the launch stream around each kernel family,
+// so bench.py can report the dominant kernel's average launch duration and achieved FLOP/s measured live in
+// the timed region (torch.cuda.Event would only see torch's current stream, and cannot bracket single launches
+// issued from C++).  Off by default; when off the cost is one branch per launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace drm {
+
+enum ProfKind { PROF_CONV3 = 0, PROF_CONV1 = 1, PROF_ATTN = 2, PROF_GNSTATS = 3, PROF_MISC = 4, PROF_KINDS = 5 };
+
+struct ProfScope {
+  int kind;
+  int slot;
+  hipStream_t s;
+  ProfScope(int kind, double flops, double bytes, hipStream_t s);
+  ~ProfScope();
+};
+
+void prof_enable(int on);
+bool prof_enabled();
+// synchronises the recorded events and accumulates; returns per-kind totals since the last reset
+void prof_collect(double ms[PROF_KINDS], double flops[PROF_KINDS], double bytes[PROF_KINDS], int64_t launches[PROF_KINDS]);
+void prof_reset();
+
+}  // namespace drm

@@ -15,7 +15,7 @@ class DrmnetSampler {
   size_t workspace_bytes(int N, int H, int W) const;
   int step(float* Lr_k, const float* LrK, const int32_t* rows, int n, int i, const float* noise, uint64_t seed, float* zk_out, float* zK_out,
            int32_t* conv_out, int B, int H, int W, Arena& ar, hipStream_t s);
-  int sample(const float* LrK, const float* noise0, const float* step_noise, uint64_t seed, int early_exit, float* Lr0, float* zK, int32_t* K,
+  int sample(const float* LrK, const float* cond, const float* noise0, const float* step_noise, uint64_t seed, int early_exit, float* Lr0, float* zK, int32_t* K,
              int32_t* steps_done, int B, int H, int W, Arena& ar, hipStream_t s);
   ~DrmnetSampler();
 

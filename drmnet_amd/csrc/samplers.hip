@@ -268,7 +268,7 @@ int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int 
   return DRM_OK;
 }
 
-int DrmnetSampler::sample(const float* LrK, const float* noise0, const float* step_noise, uint64_t seed, int early_exit, float* Lr0, float* zK,
+int DrmnetSampler::sample(const float* LrK, const float* cond, const float* noise0, const float* step_noise, uint64_t seed, int early_exit, float* Lr0, float* zK,
                           int32_t* K, int32_t* steps_done, int B, int H, int W, Arena& ar, hipStream_t s) {
   const int zd = cfg.z_dim;
   const size_t chw = (size_t)3 * H * W;
@@ -296,7 +296,7 @@ int DrmnetSampler::sample(const float* LrK, const float* noise0, const float* st
     DRM_HIP_CHECK(hipMemcpyAsync(d_rows, h_rows, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     const float* nz = step_noise ? step_noise + (size_t)i * B * chw : nullptr;
     ar.release(mark);
-    DRM_TRY(step(Lr0, LrK, d_rows, n, i, nz, seed, nullptr, nullptr, nullptr, B, H, W, ar, s));
+    DRM_TRY(step(Lr0, cond, d_rows, n, i, nz, seed, nullptr, nullptr, nullptr, B, H, W, ar, s));
     ++steps;
     if (early_exit) {
       hipLaunchKernelGGL(drmnet_record_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_rows, last, last_zKc, n, zd, i, zK, K);

@@ -1,0 +1,117 @@
+"""``DDIMSampler`` -- same surface as ldm/models/diffusion/ddim.py:16-259, loop executed by drm_ddim_sample.
+
+Schedule construction restates make_ddim_timesteps / make_ddim_sampling_parameters
+(ldm/modules/diffusionmodules/util.py:46-74) including the reference's mixed fp32/fp64 rounding sequence
+(``ndarray / Tensor`` dispatches to ``Tensor.__rtruediv__`` = reciprocal()*other), checked bit-for-bit against
+tests/golden/ddim_schedule_eta*.npz.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * 0.8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    steps_out = ddim_timesteps + 1
+    if verbose:
+        print(f"Selected timesteps for ddim sampler: {steps_out}")
+    return steps_out
+
+
+def make_ddim_sampling_parameters(alphacums: torch.Tensor, ddim_timesteps, eta, verbose=True):
+    ac = alphacums.detach().cpu().float()
+    idx = torch.from_numpy(np.asarray(ddim_timesteps))
+    alphas = ac[idx]  # fp32
+    alphas_prev = torch.tensor([float(ac[0])] + [float(v) for v in ac[idx[:-1]]], dtype=torch.float64)
+    recip = (1 - alphas).reciprocal().double()  # the one fp32-rounded factor of util.py:69
+    sigmas = eta * torch.sqrt(recip * (1 - alphas_prev) * (1 - alphas.double() / alphas_prev))
+    return sigmas, alphas, alphas_prev
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self._ws = _lib.Workspace()
+
+    def register_buffer(self, name, attr):
+        if isinstance(attr, torch.Tensor):
+            attr = attr.to(self.model.device)  # the reference hard-codes "cuda" here (ddim.py:23-27)
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose=verbose)
+        alphas_cumprod = self.model.alphas_cumprod
+        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        sig, a, a_prev = make_ddim_sampling_parameters(alphas_cumprod, self.ddim_timesteps, ddim_eta, verbose=verbose)
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sig, a, a_prev
+        self.ddim_sqrt_one_minus_alphas = torch.sqrt(1.0 - a)
+        # the five fp32 scalars p_sample_ddim derives per index through torch.full + fp32 tensor ops (ddim.py:243-258)
+        S = len(self.ddim_timesteps)
+        coef = np.zeros((S, 5), dtype=np.float32)
+        for i in range(S):
+            a_t = torch.full((1,), float(a[i]))
+            ap = torch.full((1,), float(a_prev[i]))
+            sg = torch.full((1,), float(sig[i]))
+            s1m = torch.full((1,), float(self.ddim_sqrt_one_minus_alphas[i]))
+            coef[i] = [a_t.sqrt().item(), s1m.item(), ap.sqrt().item(), (1.0 - ap - sg**2).sqrt().item(), sg.item()]
+        self.ddim_coef = coef
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None, quantize_x0=False,
+               eta=0.0, mask=None, x0=None, temperature=1.0, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None, verbose=True,
+               x_T=None, log_every_t=100, unconditional_guidance_scale=1.0, unconditional_conditioning=None, noise=None, seed=None,
+               num_steps=None, **kwargs):
+        """ddim.py:64-126.  Extra keyword-only knobs: ``noise`` [steps,N,C,H,W] injects the per-step draws (parity mode),
+        ``seed`` keys the Philox stream otherwise, ``num_steps`` truncates the chain (benchmarks)."""
+        if conditioning is not None and not isinstance(conditioning, dict):
+            if conditioning.shape[0] != batch_size:
+                print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        if any(v is not None for v in (callback, img_callback, mask, x0, score_corrector, unconditional_conditioning)) or quantize_x0:
+            raise NotImplementedError("callbacks / mask / guidance / quantize are not on the shipped path")
+        if temperature != 1.0 or noise_dropout != 0.0 or unconditional_guidance_scale != 1.0:
+            raise NotImplementedError("temperature / noise_dropout / guidance are not on the shipped path")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        size = (batch_size, *shape)
+        return self.ddim_sampling(conditioning, size, x_T=x_T, log_every_t=log_every_t, verbose=verbose, noise=noise, seed=seed, num_steps=num_steps)
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, log_every_t=100, verbose=True, noise=None, seed=None, num_steps=None, **unused):
+        """ddim.py:128-204 -> (final x, {"x_inter": [x_T, x], "pred_x0": [x_T]})."""
+        from . import ops
+
+        dev = self.model.betas.device
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())
+        img = ops.randn(shape, seed, 0, dev) if x_T is None else _lib.require_gpu_tensor(x_T, "x_T").clone()
+        x_start = img.clone()
+        c = cond[0] if isinstance(cond, (list, tuple)) else cond
+        c = _lib.require_gpu_tensor(c, "conditioning")
+        noise = None if noise is None else _lib.require_gpu_tensor(noise, "noise")
+        unet = self.model.model.diffusion_model
+        h = unet.engine_handle()
+        L = _lib.lib()
+        n, _, hh, ww = shape
+        ws = self._ws.get(int(L.drm_sampler_workspace_bytes(h, n, hh, ww)), dev)
+        ts = np.ascontiguousarray(np.asarray(self.ddim_timesteps, dtype=np.int64))
+        coef = np.ascontiguousarray(self.ddim_coef)
+        S = len(ts)
+        with torch.cuda.device(dev):
+            _lib.check(L.drm_ddim_sample(h, img.data_ptr(), c.data_ptr(), ts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         coef.ctypes.data_as(C.POINTER(C.c_float)), S, int(num_steps or 0), _lib.ptr(noise), seed, n, hh, ww,
+                                         ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+        return img, {"x_inter": [x_start, img], "pred_x0": [x_start]}

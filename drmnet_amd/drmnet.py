@@ -1,0 +1,405 @@
+"""``DRMNet`` -- host-side operator surface of the reference LightningModule, sampling on the HIP engine.
+
+Mirrors models/drmnet.py of the reference by name, signature and return values for everything the
+inference path touches (scripts/estimate.py:84-100):
+  __init__ params (configs/drmnet/eval_drmnet.yaml), ema_scope :242-258, init_from_ckpt :260-277,
+  apply_model :376-388, get_brdf_out :390-396, forward :452-456, get_schedule :458-501,
+  check_convergence :747-750, p_mean_variance :752-770, p_sample (stub) :772-780,
+  p_sample_loop :782-847, get_input_for_predict :1011-1045, decode_first_stage, r0toenvmap :931-941.
+Training (p_losses, get_input, caches, log_images, Mitsuba rendering) is out of scope.
+
+The module is a plain ``nn.Module`` (pytorch_lightning is not needed for inference); ``state_dict()`` has the
+reference's keys, so ``drmnet.ckpt`` loads with ``init_from_ckpt``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from contextlib import contextmanager
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import instantiate_from_config
+from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma, ZEmbDiffusionWrapper
+
+
+class DRMNet(nn.Module):
+    def __init__(
+        self,
+        illnet_config,
+        refnet_config,
+        renderer_config=None,
+        max_timesteps: int = 250,
+        loss_type: str = "l1",
+        ckpt_path: str = None,
+        init_from_ckpt_verbose: bool = True,
+        ignore_keys: List[str] = [],
+        monitor: str = "val/loss",
+        use_ema: bool = True,
+        input_key: str = "LrK",
+        sigma_for_cond_xK: float = 0.0,
+        image_size: int = 128,
+        channels: int = 3,
+        log_every_k: int = 5,
+        parameterization: str = "residual",
+        scheduler_config=None,
+        cond_stage_trainable: bool = False,
+        concat_mode: bool = False,
+        cond_stage_forward: Optional[str] = None,
+        conditioning_key: Optional[str] = None,
+        scale_factor: float = 1.0,
+        scale_by_std: bool = False,
+        l_refmap_weight: float = 1.0,
+        l_refcode_weight: float = 1.0,
+        sigma: float = 0.01,
+        delta: float = 0.0125,
+        gamma: float = 0.9,
+        epsilon: float = 0.001,
+        train_with_zk_gt: bool = False,
+        train_with_zk_gt_switch_epoch: Optional[int] = None,
+        brdf_param_names: List[str] = ["specular"],
+        z0: List[float] = [1.0],
+        model_emb_z: bool = True,
+        emb_z_crossattn: bool = False,
+        refmap_input_scaler: Optional[float] = None,
+        first_stage_config={"target": "ldm.models.autoencoder.IdentityFirstStage"},
+        cond_stage_config="__is_first_stage__",
+        cache_refmap: bool = False,
+        refmap_cache_root: Optional[str] = None,
+        envmap_dir: Optional[str] = None,
+        basis_r0: Optional[torch.Tensor] = None,
+    ):
+        super().__init__()
+        assert parameterization in ["residual"], 'currently only supporting "residual"'
+        self.parameterization = parameterization
+        self.log_every_k = log_every_k
+        self.input_key = input_key
+        self.sigma_for_cond_xK = sigma_for_cond_xK
+        self.image_size = image_size
+        self.channels = channels
+        self.max_timesteps = max_timesteps
+        self.brdf_param_names = brdf_param_names
+        self.gamma = gamma
+        self.epsilon = epsilon
+        self._z0 = torch.tensor(z0, dtype=torch.float32)
+        self.zdim = len(self._z0)
+        self.register_buffer("z0", self._z0)
+        self.instantiate_brdf_model(renderer_config, basis_r0)
+
+        assert concat_mode, "This model only supports concat mode"
+        if conditioning_key is None:
+            conditioning_key = "concat" if concat_mode else "crossattn"
+        if cond_stage_config == "__is_unconditional__":
+            conditioning_key = None
+        self.illnet_model = ZEmbDiffusionWrapper(illnet_config, conditioning_key, self.zdim, model_emb_z, emb_z_crossattn)
+        self.refnet_model = DiffusionWrapper(refnet_config, conditioning_key)
+        self.use_ema = use_ema
+        if self.use_ema:
+            self.illnet_model_ema = LitEma(self.illnet_model)
+            self.refnet_model_ema = LitEma(self.refnet_model)
+        self.use_scheduler = scheduler_config is not None
+        self.l_refmap_weight = l_refmap_weight
+        self.l_refcode_weight = l_refcode_weight
+        if monitor is not None:
+            self.monitor = monitor
+        self.concat_mode = concat_mode
+        self.cond_stage_trainable = cond_stage_trainable
+        self.scale_by_std = scale_by_std
+        if scale_by_std:
+            raise NotImplementedError("scale_by_std is training-only")
+        self.scale_factor = scale_factor
+        self.first_stage_model = instantiate_from_config(first_stage_config).eval()
+        if not isinstance(self.first_stage_model, IdentityFirstStage):
+            raise NotImplementedError("only IdentityFirstStage is used by the shipped configs")
+        assert cond_stage_config == "__is_first_stage__" or cond_stage_config == "__is_unconditional__"
+        self.cond_stage_model = self.first_stage_model if cond_stage_config == "__is_first_stage__" else None
+        self.cond_stage_forward = cond_stage_forward
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, verbose=init_from_ckpt_verbose)
+        self.loss_type = loss_type
+        self.sigma = sigma
+        self.delta = delta
+        self.refmap_input_scaler = refmap_input_scaler
+        self.eval()
+        self._sampler = None
+        self._sampler_sig = None
+        self._ws = _lib.Workspace()
+
+    # ------------------------------------------------------------------ plumbing kept from the reference
+    @property
+    def device(self):
+        return self.z0.device
+
+    def instantiate_brdf_model(self, config, basis_r0=None):
+        """Reference renders basis_r0 (white envmap, BRDF z0) through Mitsuba (drmnet.py:328-347). Out of scope here:
+        basis_r0 is an optional input (ones by default) -- see DESIGN.md."""
+        self.renderer = instantiate_from_config(config) if config is not None else None
+        if basis_r0 is None:
+            basis_r0 = torch.ones(3, self.image_size, self.image_size)
+        self.register_buffer("basis_r0", basis_r0.float(), persistent=False)
+
+    @contextmanager
+    def ema_scope(self, context=None):
+        if self.use_ema:
+            self.illnet_model_ema.store(self.illnet_model.parameters())
+            self.refnet_model_ema.store(self.refnet_model.parameters())
+            self.illnet_model_ema.copy_to(self.illnet_model)
+            self.refnet_model_ema.copy_to(self.refnet_model)
+            if context is not None:
+                print(f"{context}: Switched to EMA weights")
+        try:
+            yield None
+        finally:
+            if self.use_ema:
+                self.illnet_model_ema.restore(self.illnet_model.parameters())
+                self.refnet_model_ema.restore(self.refnet_model.parameters())
+                if context is not None:
+                    print(f"{context}: Restored training weights")
+
+    def init_from_ckpt(self, path, ignore_keys=list(), only_model=False, verbose=True):
+        sd = torch.load(path, map_location="cpu")
+        if "state_dict" in list(sd.keys()):
+            sd = sd["state_dict"]
+        for k in list(sd.keys()):
+            for ik in ignore_keys:
+                if k.startswith(ik):
+                    print("Deleting key {} from state_dict.".format(k))
+                    del sd[k]
+        missing, unexpected = self.load_state_dict(sd, strict=False) if not only_model else self.illnet_model.load_state_dict(sd, strict=False)
+        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+        if len(missing) > 0 and verbose:
+            print(f"Missing Keys: {missing}")
+        if len(unexpected) > 0 and verbose:
+            print(f"Unexpected Keys: {unexpected}")
+
+    @torch.no_grad()
+    def encode_first_stage(self, x):
+        return self.first_stage_model.encode(x)
+
+    def get_first_stage_encoding(self, encoder_posterior):
+        assert isinstance(encoder_posterior, torch.Tensor)
+        return self.scale_factor * encoder_posterior
+
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        z = 1.0 / self.scale_factor * z  # LatentDiffusion.decode_first_stage, ddpm.py:731-789 (identity first stage)
+        return self.first_stage_model.decode(z)
+
+    # ------------------------------------------------------------------ per-step pieces (reference semantics)
+    def apply_model(self, model: DiffusionWrapper, input_refmap: torch.Tensor, k: Union[torch.Tensor, int], cond, rows=None):
+        if not isinstance(cond, dict):
+            if not isinstance(cond, list):
+                cond = [cond]
+            key = "c_concat" if model.conditioning_key == "concat" else "c_crossattn"
+            cond = {key: cond}
+        if isinstance(k, int):
+            n = input_refmap.size(0) if rows is None else rows.numel()
+            k = torch.full((n,), k, device=input_refmap.device)
+        return model(input_refmap, k, rows=rows, **cond)
+
+    def get_schedule(self, zK, z0=None, reversed_k=None, normalized_k=None, return_zkm1=False, power_precision=torch.double):
+        """drmnet.py:458-501 (tiny [n, z_dim] host-side math; the sampler kernels restate the reversed_k branch)."""
+        z0 = self.z0 if z0 is None else z0.to(zK.device)
+        Delta_K = zK - z0
+        log_gamma = math.log(self.gamma)
+        distance = torch.linalg.norm(Delta_K, dim=-1)
+        K = (torch.log(self.epsilon / distance) / math.log(self.gamma)).int() + 2
+        assert (normalized_k is None) ^ (reversed_k is None), "normalized_k and reversed_k are exclusive"
+        if normalized_k is not None:
+            K = K.clip(min=1).int()
+            k = (normalized_k * K).int()
+            reversed_k = K - k - 1
+        else:
+            k = K - reversed_k - 1
+            if isinstance(reversed_k, int):
+                reversed_k = torch.tensor([reversed_k], device=zK.device)
+        reversed_k = reversed_k.to(power_precision)
+        Delta_k = torch.exp(reversed_k.unsqueeze(-1) * log_gamma).float() * Delta_K
+        zk = Delta_k + z0
+        if return_zkm1:
+            zkm1 = torch.exp((reversed_k + 1).unsqueeze(-1) * math.log(self.gamma)).float() * Delta_K + z0
+            return K, k, zk, zkm1
+        return K, k, zk
+
+    def get_brdf_out(self, brdf_model_out, reversed_k=None):
+        zK = brdf_model_out
+        _, _, zk = self.get_schedule(zK, reversed_k=reversed_k)
+        if not self.training:
+            zk = zk.clamp(0, 1)
+            zK = zK.clamp(0, 1)
+        return zk, zK
+
+    def check_convergence(self, zk):
+        distance = torch.linalg.norm((zk - self.z0).abs(), dim=-1)
+        return torch.logical_or(distance < self.epsilon, distance == 0)
+
+    def forward(self, Lr_k, illnet_cond, refnet_cond, reversed_k):
+        z_out = self.apply_model(self.refnet_model, Lr_k, reversed_k, refnet_cond)
+        zk, _ = self.get_brdf_out(z_out, reversed_k=reversed_k)
+        Delta = zk - self.z0
+        return self.apply_model(self.illnet_model, Lr_k, Delta, illnet_cond), z_out
+
+    def p_mean_variance(self, Lr_k, illnet_cond, refnet_cond, reversed_k, return_model_out=False):
+        model_out, z_out = self(Lr_k, illnet_cond, refnet_cond, reversed_k)
+        model_mean = Lr_k + model_out
+        if return_model_out:
+            return model_mean, self.delta, z_out, model_out
+        return model_mean, self.delta, z_out
+
+    def p_sample(self, Lr_k, illnet_cond, refnet_cond, reversed_k, return_model_out=False):
+        raise NotImplementedError("")  # the reference leaves this unimplemented too (drmnet.py:772-780)
+
+    # ------------------------------------------------------------------ the device sampler
+    def _engine(self):
+        ill, ref = self.illnet_model.diffusion_model, self.refnet_model.diffusion_model
+        hi, hr = ill.engine_handle(), ref.engine_handle()
+        zp = [p.detach() for p in self.illnet_model.z_emb_params()]
+        for p in zp:
+            _lib.require_gpu_tensor(p, "z_emb_layer parameter")
+        sig = (hi.value, hr.value, tuple((p.data_ptr(), p._version) for p in zp), float(self.gamma), float(self.epsilon), float(self.delta),
+               int(self.max_timesteps), tuple(self._z0.tolist()))
+        if self._sampler is not None and sig == self._sampler_sig:
+            return self._sampler
+        self._free_sampler()
+        cfg = _lib.DrmnetCfg()
+        cfg.z_dim = self.zdim
+        cfg.max_timesteps = int(self.max_timesteps)
+        cfg.gamma = float(self.gamma)
+        cfg.epsilon = float(self.epsilon)
+        cfg.delta = float(self.delta)
+        for i, v in enumerate(self._z0.tolist()):
+            cfg.z0[i] = v
+        h = C.c_void_p()
+        torch.cuda.current_stream(zp[0].device).synchronize()
+        with torch.cuda.device(zp[0].device):
+            _lib.check(_lib.lib().drm_drmnet_create(hi, hr, _lib.ptr_array(zp), C.byref(cfg), C.byref(h)))
+        self._sampler, self._sampler_sig = h, sig
+        return h
+
+    def _free_sampler(self):
+        if getattr(self, "_sampler", None) is not None:
+            _lib.lib().drm_drmnet_destroy(self._sampler)
+            self._sampler = None
+
+    def __del__(self):
+        try:
+            self._free_sampler()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _one_cond(cond, LrK):
+        c = cond[0] if isinstance(cond, (list, tuple)) else cond
+        if isinstance(cond, (list, tuple)) and len(cond) != 1:
+            raise NotImplementedError("one concat conditioning tensor expected")
+        return _lib.require_gpu_tensor(c, "cond")
+
+    @torch.no_grad()
+    def p_sample_loop(self, Lr_K, illnet_cond, refnet_cond, return_intermediates=False, verbose=True, log_every_k=None,
+                      noise0=None, step_noise=None, seed=None, early_exit=True):
+        """drmnet.py:782-847.  Extra keyword-only knobs (not in the reference): ``noise0`` [B,3,H,W] and ``step_noise``
+        [max_timesteps,B,3,H,W] inject the random draws (parity mode; row b of step_noise[i] is used by sample b iff it is
+        still active and not converged at step i); otherwise noise comes from the library's Philox stream keyed by ``seed``
+        (drawn from torch's generator when None).  ``early_exit=False`` keeps every sample active for max_timesteps steps.
+        Returns (Lr_0, zK, K[, intermediates]) exactly as the reference."""
+        log_every_k = log_every_k or self.log_every_k
+        LrK = _lib.require_gpu_tensor(Lr_K, "Lr_K")
+        dev = LrK.device
+        cond = self._one_cond(illnet_cond, LrK)
+        cond_r = self._one_cond(refnet_cond, LrK)
+        if cond_r.data_ptr() != cond.data_ptr() and not torch.equal(cond_r, cond):
+            raise NotImplementedError("illnet_cond and refnet_cond are the same tensor on the shipped path (drmnet.py:1043)")
+        B, _, H, W = LrK.shape
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())
+        noise0 = None if noise0 is None else _lib.require_gpu_tensor(noise0, "noise0")
+        step_noise = None if step_noise is None else _lib.require_gpu_tensor(step_noise, "step_noise")
+        if step_noise is not None and tuple(step_noise.shape) != (self.max_timesteps, B, 3, H, W):
+            raise RuntimeError("step_noise must be [max_timesteps, B, 3, H, W]")
+        h = self._engine()
+        L = _lib.lib()
+        ws = self._ws.get(int(L.drm_drmnet_workspace_bytes(h, B, H, W)), dev)
+        Lr0 = torch.empty_like(LrK)
+        zK = torch.empty((B, self.zdim), dtype=torch.float32, device=dev)
+        K = torch.empty((B,), dtype=torch.int32, device=dev)
+        if not return_intermediates:
+            steps = C.c_int32(0)
+            with torch.cuda.device(dev):
+                _lib.check(L.drm_drmnet_sample(h, LrK.data_ptr(), cond.data_ptr(), _lib.ptr(noise0), _lib.ptr(step_noise), seed, int(bool(early_exit)),
+                                               Lr0.data_ptr(), zK.data_ptr(), K.data_ptr(), C.byref(steps), B, H, W, ws.data_ptr(), ws.numel(),
+                                               _lib.stream_ptr(dev)))
+            self.last_steps = int(steps.value)
+            return Lr0, zK, K
+        # intermediates requested: drive the loop from the host, one drm_drmnet_step per iteration (same kernels)
+        from . import ops
+
+        n0 = noise0 if noise0 is not None else ops.randn(LrK.shape, seed, 0, dev)
+        Lr_k = LrK + self.delta * n0
+        intermediates = {"Lrk_inter": [Lr_k.clone()], "zk_inter": []}
+        zK.fill_(float("nan"))
+        K.fill_(self.max_timesteps)
+        active = torch.arange(B, dtype=torch.int32, device=dev)
+        for i in range(self.max_timesteps):
+            n = active.numel()
+            zk = torch.empty((n, self.zdim), device=dev)
+            zKc = torch.empty((n, self.zdim), device=dev)
+            conv = torch.empty((n,), dtype=torch.int32, device=dev)
+            nz = None if step_noise is None else step_noise[i]
+            with torch.cuda.device(dev):
+                _lib.check(L.drm_drmnet_step(h, Lr_k.data_ptr(), cond.data_ptr(), active.data_ptr(), n, i, _lib.ptr(nz), seed, zk.data_ptr(),
+                                             zKc.data_ptr(), conv.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+            if i % log_every_k == 0:
+                z_log = torch.full((B, self.zdim), float("nan"), device=dev)
+                z_log[active.long()] = zk
+                intermediates["zk_inter"].append(z_log)
+                Lr_log = torch.zeros_like(Lr_k)
+                Lr_log[active.long()] = Lr_k[active.long()]
+                intermediates["Lrk_inter"].append(Lr_log)
+            if early_exit:
+                cb = conv.bool()
+                done = active[cb].long()
+                K[done] = i + 1
+                zK[done] = zKc[cb]
+                active = active[~cb].contiguous()
+                if active.numel() == 0:
+                    break
+        return Lr_k, zK, K, intermediates
+
+    # ------------------------------------------------------------------ estimate.py glue
+    @torch.no_grad()
+    def get_input_for_predict(self, batch, bs: Optional[int] = None):
+        """drmnet.py:1011-1045: luminance geometric-mean scaling to refmap_input_scaler, ds.transform, conds = [LrK]."""
+        LrK = batch[self.input_key]
+        bs = min(len(LrK), bs) if bs is not None else len(LrK)
+        LrK = LrK[:bs]
+        if self.refmap_input_scaler is not None:
+            L = 0.212671 * LrK[:, 0] + 0.715160 * LrK[:, 1] + 0.072169 * LrK[:, 2]
+            self.normalizing_scale = self.refmap_input_scaler / torch.exp(
+                (torch.log(L.clip(1e-5)) * (L > 0)).sum(dim=(1, 2)) / (L > 0).sum(dim=(1, 2))
+            )
+            LrK = LrK * self.normalizing_scale[:, None, None, None]
+        LrK = self.ds.transform(LrK)
+        Lr0 = batch.get("Lr0")
+        if Lr0 is not None:
+            if self.refmap_input_scaler is not None:
+                Lr0 = Lr0[:bs] * self.normalizing_scale[:, None, None, None]
+            Lr0 = self.ds.transform(Lr0)
+        LrK = self.get_first_stage_encoding(self.encode_first_stage(LrK))
+        tag = batch["tag"][:bs]
+        cond_LrK = LrK
+        if self.sigma_for_cond_xK > 0:
+            cond_LrK = self.sigma_for_cond_xK * torch.randn_like(LrK) + cond_LrK
+        illnet_c = [cond_LrK]
+        refnet_c = illnet_c
+        return LrK, Lr0, illnet_c, refnet_c, tag
+
+    def r0toenvmap(self, r0: torch.Tensor, envshape: Optional[Tuple[int]] = None) -> torch.Tensor:
+        """drmnet.py:931-941: divide by basis_r0, warp the mirror map to a lat-long envmap -> [B, H, W, 3]."""
+        from .transform import mirmap2envmap
+
+        if envshape is None:
+            envshape = (self.image_size, self.image_size * 2)
+        r0 = r0 / self.basis_r0
+        return mirmap2envmap(r0, envshape).permute(0, 2, 3, 1)

@@ -1,0 +1,368 @@
+"""``ObsNetDiffusion`` -- host-side operator surface of the reference's conditional DDPM, sampling on the HIP engine.
+
+Mirrors (inference half only; training, VQ/KL first stages, patch fold/unfold are out of scope):
+  DDPM.__init__/register_schedule/ema_scope/init_from_ckpt        ldm/models/diffusion/ddpm.py:59-231
+  DDPM.predict_start_from_noise / q_posterior / q_sample          ddpm.py:233-246, :306-312
+  LatentDiffusion.__init__/apply_model/p_mean_variance/p_sample/sample/decode_first_stage
+                                                                  ddpm.py:439-488, :916-1023, :1079-1167, :1315-1350, :731-789
+  ObsNetDiffusion.__init__/p_sample_loop/sample_log/get_cond_for_predict   models/obsnet.py:35-137, :500-583, :656-704
+``state_dict()`` keys equal the reference's (schedule buffers, ``model.diffusion_model.*``, ``model_ema.*``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from contextlib import contextmanager
+from functools import partial
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import instantiate_from_config
+from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """ldm/modules/diffusionmodules/util.py:21-43 ("linear" is what every shipped config uses)."""
+    if schedule == "linear":
+        betas = torch.linspace(linear_start**0.5, linear_end**0.5, n_timestep, dtype=torch.float64) ** 2
+    elif schedule == "sqrt_linear":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+    elif schedule == "sqrt":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+    else:
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    return betas.numpy()
+
+
+def extract_into_tensor(a, t, x_shape):
+    b, *_ = t.shape
+    out = a.gather(-1, t)
+    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+class DDPM(nn.Module):
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", loss_type="l2", ckpt_path=None, ignore_keys=[],
+                 load_only_unet=False, monitor="val/loss", use_ema=True, first_stage_key="image", image_size=256, channels=3, log_every_t=100,
+                 clip_denoised=True, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3, given_betas=None, original_elbo_weight=0.0,
+                 v_posterior=0.0, l_simple_weight=1.0, conditioning_key=None, parameterization="eps", scheduler_config=None,
+                 use_positional_encodings=False, learn_logvar=False, logvar_init=0.0):
+        super().__init__()
+        assert parameterization in ["eps", "x0"], 'currently only supporting "eps" and "x0"'
+        if parameterization != "eps":
+            raise NotImplementedError("only eps-prediction is on the shipped path")
+        self.parameterization = parameterization
+        self.cond_stage_model = None
+        self.clip_denoised = clip_denoised
+        self.log_every_t = log_every_t
+        self.first_stage_key = first_stage_key
+        self.image_size = image_size
+        self.channels = channels
+        self.use_positional_encodings = use_positional_encodings
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.use_ema = use_ema
+        if self.use_ema:
+            self.model_ema = LitEma(self.model)
+        self.v_posterior = v_posterior
+        self.original_elbo_weight = original_elbo_weight
+        self.l_simple_weight = l_simple_weight
+        if monitor is not None:
+            self.monitor = monitor
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, only_model=load_only_unet)
+        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
+                               linear_end=linear_end, cosine_s=cosine_s)
+        self.loss_type = loss_type
+        self.learn_logvar = learn_logvar
+        if learn_logvar:
+            raise NotImplementedError("learn_logvar is training-only")
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+        """fp64 numpy tables cast to fp32 buffers, ddpm.py:137-187 (same names, same order)."""
+        betas = given_betas if given_betas is not None else make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end, cosine_s)
+        alphas = 1.0 - betas
+        alphas_cumprod = np.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = np.append(1.0, alphas_cumprod[:-1])
+        (timesteps,) = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.linear_start = linear_start
+        self.linear_end = linear_end
+        to_torch = partial(torch.tensor, dtype=torch.float32)
+        self.register_buffer("betas", to_torch(betas))
+        self.register_buffer("alphas_cumprod", to_torch(alphas_cumprod))
+        self.register_buffer("alphas_cumprod_prev", to_torch(alphas_cumprod_prev))
+        self.register_buffer("sqrt_alphas_cumprod", to_torch(np.sqrt(alphas_cumprod)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", to_torch(np.sqrt(1.0 - alphas_cumprod)))
+        self.register_buffer("log_one_minus_alphas_cumprod", to_torch(np.log(1.0 - alphas_cumprod)))
+        self.register_buffer("sqrt_recip_alphas_cumprod", to_torch(np.sqrt(1.0 / alphas_cumprod)))
+        self.register_buffer("sqrt_recipm1_alphas_cumprod", to_torch(np.sqrt(1.0 / alphas_cumprod - 1)))
+        posterior_variance = (1 - self.v_posterior) * betas * (1.0 - alphas_cumprod_prev) / (1.0 - alphas_cumprod) + self.v_posterior * betas
+        self.register_buffer("posterior_variance", to_torch(posterior_variance))
+        self.register_buffer("posterior_log_variance_clipped", to_torch(np.log(np.maximum(posterior_variance, 1e-20))))
+        self.register_buffer("posterior_mean_coef1", to_torch(betas * np.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod)))
+        self.register_buffer("posterior_mean_coef2", to_torch((1.0 - alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - alphas_cumprod)))
+
+    @contextmanager
+    def ema_scope(self, context=None):
+        if self.use_ema:
+            self.model_ema.store(self.model.parameters())
+            self.model_ema.copy_to(self.model)
+            if context is not None:
+                print(f"{context}: Switched to EMA weights")
+        try:
+            yield None
+        finally:
+            if self.use_ema:
+                self.model_ema.restore(self.model.parameters())
+                if context is not None:
+                    print(f"{context}: Restored training weights")
+
+    def init_from_ckpt(self, path, ignore_keys=list(), only_model=False, verbose=True):
+        sd = torch.load(path, map_location="cpu")
+        if "state_dict" in list(sd.keys()):
+            sd = sd["state_dict"]
+        for k in list(sd.keys()):
+            for ik in ignore_keys:
+                if k.startswith(ik):
+                    print("Deleting key {} from state_dict.".format(k))
+                    del sd[k]
+        missing, unexpected = self.load_state_dict(sd, strict=False) if not only_model else self.model.load_state_dict(sd, strict=False)
+        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+        if len(missing) > 0 and verbose:
+            print(f"Missing Keys: {missing}")
+        if len(unexpected) > 0 and verbose:
+            print(f"Unexpected Keys: {unexpected}")
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = (extract_into_tensor(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                + extract_into_tensor(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        return mean, extract_into_tensor(self.posterior_variance, t, x_t.shape), extract_into_tensor(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        return (extract_into_tensor(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
+                + extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+
+
+class LatentDiffusion(DDPM):
+    def __init__(self, first_stage_config, cond_stage_config, num_timesteps_cond=None, cond_stage_key="image", cond_stage_trainable=False,
+                 concat_mode=True, cond_stage_forward=None, conditioning_key=None, scale_factor=1.0, scale_by_std=False, *args, **kwargs):
+        self.num_timesteps_cond = 1 if num_timesteps_cond is None else num_timesteps_cond
+        self.scale_by_std = scale_by_std
+        assert self.num_timesteps_cond <= kwargs["timesteps"]
+        if conditioning_key is None:
+            conditioning_key = "concat" if concat_mode else "crossattn"
+        if cond_stage_config == "__is_unconditional__":
+            conditioning_key = None
+        ckpt_path = kwargs.pop("ckpt_path", None)
+        ignore_keys = kwargs.pop("ignore_keys", [])
+        super().__init__(conditioning_key=conditioning_key, *args, **kwargs)
+        self.concat_mode = concat_mode
+        self.cond_stage_trainable = cond_stage_trainable
+        self.cond_stage_key = cond_stage_key
+        self.num_downs = 0
+        if scale_by_std:
+            raise NotImplementedError("scale_by_std is training-only")
+        self.scale_factor = scale_factor
+        self.first_stage_model = instantiate_from_config(first_stage_config).eval()
+        if not isinstance(self.first_stage_model, IdentityFirstStage):
+            raise NotImplementedError("only IdentityFirstStage is used by the shipped configs")
+        if cond_stage_config == "__is_first_stage__":
+            self.cond_stage_model = self.first_stage_model
+        elif cond_stage_config == "__is_unconditional__":
+            self.cond_stage_model = None
+        else:
+            raise NotImplementedError("separate cond_stage_config is not on the shipped path")
+        self.cond_stage_forward = cond_stage_forward
+        self.clip_denoised = False
+        self.shorten_cond_schedule = self.num_timesteps_cond > 1
+        if self.shorten_cond_schedule:
+            raise NotImplementedError("num_timesteps_cond > 1 is not on the shipped path")
+        self.restarted_from_ckpt = False
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+            self.restarted_from_ckpt = True
+        self._ws = _lib.Workspace()
+
+    def get_learned_conditioning(self, c):
+        if self.cond_stage_forward is None:
+            if hasattr(self.cond_stage_model, "encode") and callable(self.cond_stage_model.encode):
+                return self.cond_stage_model.encode(c)
+            return self.cond_stage_model(c)
+        return getattr(self.cond_stage_model, self.cond_stage_forward)(c)
+
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        return self.first_stage_model.decode(1.0 / self.scale_factor * z)
+
+    def apply_model(self, x_noisy, t, cond, return_ids=False):
+        """ddpm.py:916-926,1017-1023: one U-Net forward on cat([x, cond], 1) (the cat is folded into the engine)."""
+        if not isinstance(cond, dict):
+            if not isinstance(cond, list):
+                cond = [cond]
+            key = "c_concat" if self.model.conditioning_key == "concat" else "c_crossattn"
+            cond = {key: cond}
+        return self.model(x_noisy, t, **cond)
+
+    def p_mean_variance(self, x, c, t, clip_denoised: bool, return_x0=False, **unused):
+        model_out = self.apply_model(x, t, c)
+        x_recon = self.predict_start_from_noise(x, t=t, noise=model_out)
+        if clip_denoised:
+            x_recon.clamp_(-1.0, 1.0)
+        model_mean, posterior_variance, posterior_log_variance = self.q_posterior(x_start=x_recon, x_t=x, t=t)
+        if return_x0:
+            return model_mean, posterior_variance, posterior_log_variance, x_recon
+        return model_mean, posterior_variance, posterior_log_variance
+
+    @torch.no_grad()
+    def p_sample(self, x, c, t, clip_denoised=False, repeat_noise=False, return_x0=False, temperature=1.0, noise=None, **unused):
+        """Single ancestral step (ddpm.py:1120-1167) -- per-step drop-in; the fused loop is ``p_sample_loop``."""
+        b = x.shape[0]
+        outs = self.p_mean_variance(x=x, c=c, t=t, clip_denoised=clip_denoised, return_x0=return_x0)
+        model_mean, _, model_log_variance = outs[:3]
+        noise = (torch.randn_like(x) if noise is None else noise) * temperature
+        nonzero_mask = (1 - (t == 0).float()).reshape(b, *((1,) * (len(x.shape) - 1)))
+        out = model_mean + nonzero_mask * (0.5 * model_log_variance).exp() * noise
+        return (out, outs[3]) if return_x0 else out
+
+    def ddpm_coef_table(self) -> np.ndarray:
+        """[T,5] fp32: sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1/2, exp(0.5*logvar)."""
+        tab = torch.stack([self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
+                           self.posterior_mean_coef2, (0.5 * self.posterior_log_variance_clipped).exp()], dim=1)
+        return np.ascontiguousarray(tab.detach().cpu().numpy().astype(np.float32))
+
+    @torch.no_grad()
+    def _ddpm_loop(self, cond, shape, x_T=None, timesteps=None, start_T=None, noise=None, seed=None):
+        dev = self.betas.device
+        c = cond[0] if isinstance(cond, (list, tuple)) else cond
+        c = _lib.require_gpu_tensor(c, "cond")
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())
+        from . import ops
+
+        img = ops.randn(shape, seed, 0, dev) if x_T is None else _lib.require_gpu_tensor(x_T, "x_T").clone()
+        T = self.num_timesteps if timesteps is None else timesteps
+        if start_T is not None:
+            T = min(T, start_T)
+        noise = None if noise is None else _lib.require_gpu_tensor(noise, "noise")
+        unet = self.model.diffusion_model
+        h = unet.engine_handle()
+        L = _lib.lib()
+        n, _, hh, ww = shape
+        ws = self._ws.get(int(L.drm_sampler_workspace_bytes(h, n, hh, ww)), dev)
+        pred_x0 = torch.empty_like(img)
+        coef = self.ddpm_coef_table()
+        with torch.cuda.device(dev):
+            _lib.check(L.drm_ddpm_sample(h, img.data_ptr(), pred_x0.data_ptr(), c.data_ptr(), coef.ctypes.data_as(C.POINTER(C.c_float)), T,
+                                         int(bool(self.clip_denoised)), _lib.ptr(noise), seed, n, hh, ww, ws.data_ptr(), ws.numel(),
+                                         _lib.stream_ptr(dev)))
+        return img, pred_x0
+
+    @torch.no_grad()
+    def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, noise=None, seed=None):
+        """ddpm.py:1253-1313 -> final img.  (intermediates: only the endpoints are kept; the loop runs on the device.)"""
+        if mask is not None or callback is not None or img_callback is not None or quantize_denoised:
+            raise NotImplementedError("mask / callbacks / quantize are not on the shipped path")
+        img, _ = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed)
+        if return_intermediates:
+            return img, [img]
+        return img
+
+    @torch.no_grad()
+    def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None, quantize_denoised=False,
+               mask=None, x0=None, shape=None, **kwargs):
+        if shape is None:
+            shape = (batch_size, self.channels, self.image_size, self.image_size)
+        if cond is not None:
+            cond = [c[:batch_size] for c in cond] if isinstance(cond, list) else cond[:batch_size]
+        return self.p_sample_loop(cond, shape, return_intermediates=return_intermediates, x_T=x_T, verbose=verbose, timesteps=timesteps,
+                                  quantize_denoised=quantize_denoised, mask=mask, x0=x0, **kwargs)
+
+
+class ObsNetDiffusion(LatentDiffusion):
+    """inpainting class (models/obsnet.py:35)."""
+
+    def __init__(self, renderer_config=None, img_renderer_config=None, num_timesteps_cond=None, cond_stage_key="image", padding_mode="noise",
+                 cond_stage_trainable=False, concat_mode=True, cond_stage_forward=None, conditioning_key=None, scale_factor=1.0,
+                 scale_by_std=False, ddim_steps: Optional[int] = None, ddim_eta: float = 1.0, masked_loss: bool = True,
+                 noisy_observe: float = 0.0, obj_img_key=None, init_from_ckpt_verbose=True, cache_data: bool = False, refmap_cache_root=None,
+                 objimg_cache_root=None, envmap_dir=None, first_stage_config={"target": "ldm.models.autoencoder.IdentityFirstStage"},
+                 cond_stage_config="__is_first_stage__", *args, **kwargs):
+        ckpt_path = kwargs.pop("ckpt_path", None)
+        ignore_keys = kwargs.pop("ignore_keys", [])
+        super().__init__(first_stage_config, cond_stage_config, num_timesteps_cond=num_timesteps_cond, cond_stage_key=cond_stage_key,
+                         cond_stage_trainable=cond_stage_trainable, concat_mode=concat_mode, cond_stage_forward=cond_stage_forward,
+                         conditioning_key=conditioning_key, scale_factor=scale_factor, scale_by_std=scale_by_std, *args, **kwargs)
+        self.renderer = instantiate_from_config(renderer_config) if renderer_config is not None else None
+        self.padding_mode = padding_mode
+        self.restarted_from_ckpt = False
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys, verbose=init_from_ckpt_verbose)
+            self.restarted_from_ckpt = True
+        self.masked_loss = masked_loss
+        self.noisy_observe = noisy_observe
+        self.obj_img_key = obj_img_key
+        self.ddim_steps = ddim_steps
+        self.ddim_eta = ddim_eta
+        self.eval()
+
+    @torch.no_grad()
+    def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, noise=None, seed=None):
+        """models/obsnet.py:500-564: like LatentDiffusion.p_sample_loop but returns pred_x0 of the LAST step."""
+        if mask is not None or callback is not None or img_callback is not None or quantize_denoised:
+            raise NotImplementedError("mask / callbacks / quantize are not on the shipped path")
+        img, pred_x0 = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed)
+        if return_intermediates:
+            return pred_x0, {"x_inter": [img], "pred_x0": [pred_x0]}
+        return pred_x0
+
+    @torch.no_grad()
+    def sample_log(self, cond, batch_size, ddim, ddim_steps, **kwargs):
+        """models/obsnet.py:566-583."""
+        if ddim:
+            from .ddim import DDIMSampler
+
+            ddim_sampler = DDIMSampler(self)
+            shape = (self.channels, self.image_size, self.image_size)
+            samples, intermediates = ddim_sampler.sample(
+                ddim_steps, batch_size, shape, cond, verbose=False,
+                log_every_t=kwargs.pop("log_every_t", None) or max(self.log_every_t * ddim_steps // self.num_timesteps, 1), **kwargs)
+        else:
+            samples, intermediates = self.sample(cond=cond, batch_size=batch_size, return_intermediates=True, **kwargs)
+        return samples, intermediates
+
+    @torch.no_grad()
+    def get_cond_for_predict(self, batch: Dict[str, Union[torch.Tensor, str]], bs: Optional[int] = None, force_c_encode: bool = False,
+                             noise: Optional[torch.Tensor] = None):
+        """models/obsnet.py:656-704 (cond_stage_key == 'raw_refmap').  The reference's in-place ``cond += ...`` also mutates
+        ``c`` because IdentityFirstStage.encode returns the same tensor (SURVEY.md 7 'bug-compat aliasing'); restated explicitly:
+        c = raw_refmap*mask + (1-mask)*noise."""
+        if self.model.conditioning_key is None:
+            mask = batch.get("mask")
+            return None, (mask[:bs, None].float() if mask is not None else None), batch["tag"][:bs]
+        if self.cond_stage_key != "raw_refmap":
+            raise NotImplementedError(self.cond_stage_key)
+        mask = batch["raw_refmask"][:bs, None].float()
+        raw_refmap = self.ds.transform(batch["raw_refmap"][:bs], dynamic_normalize=True, mask=mask)
+        cond = raw_refmap * mask
+        if self.noisy_observe > 0:
+            cond = self.noisy_observe * torch.randn_like(cond) + cond
+        c = self.get_learned_conditioning(cond.to(self.device))
+        mask = torch.nn.functional.interpolate(mask, size=(self.image_size, self.image_size))
+        if self.padding_mode == "noise":
+            nz = torch.randn_like(c) if noise is None else noise
+            c = c + (1 - mask) * nz
+        elif self.padding_mode != "zeros":
+            raise NotImplementedError()
+        return c, mask, batch["tag"][:bs]

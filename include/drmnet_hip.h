@@ -123,12 +123,13 @@ int drm_drmnet_step(drm_drmnet* s, float* Lr_k, const float* LrK, const int32_t*
                     uint64_t seed, float* zk_out, float* zK_out, int32_t* converged_out, int B, int H, int W, void* workspace,
                     size_t workspace_bytes, void* stream);
 
-/* DRMNet.p_sample_loop (models/drmnet.py:782-847): LrK [B,3,H,W] -> Lr0 [B,3,H,W], zK [B,z_dim] (NaN if never
+/* DRMNet.p_sample_loop (models/drmnet.py:782-847): LrK [B,3,H,W] (+ cond [B,3,H,W], the concat conditioning of both
+ * nets; == LrK unless sigma_for_cond_xK > 0, models/drmnet.py:1037-1043) -> Lr0 [B,3,H,W], zK [B,z_dim] (NaN if never
  * converged), K int32[B].  noise0 [B,3,H,W] / step_noise [max_timesteps,B,3,H,W] or NULL (Philox).
  * early_exit = 0 keeps every row active for max_timesteps steps (countable-steps benchmark mode).
  * Synchronises the stream once per step to read the convergence flags (the reference does the same,
  * models/drmnet.py:841).  steps_done returns the number of executed steps. */
-int drm_drmnet_sample(drm_drmnet* s, const float* LrK, const float* noise0, const float* step_noise, uint64_t seed, int early_exit,
+int drm_drmnet_sample(drm_drmnet* s, const float* LrK, const float* cond, const float* noise0, const float* step_noise, uint64_t seed, int early_exit,
                       float* Lr0, float* zK, int32_t* K, int32_t* steps_done, int B, int H, int W, void* workspace, size_t workspace_bytes,
                       void* stream);
 
@@ -147,6 +148,15 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
                     const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 
 size_t drm_sampler_workspace_bytes(const drm_unet* net, int N, int H, int W);
+
+/* Launch profiler (HIP events on the launch stream around each kernel family; used by bench.py for the roofline
+ * object).  Kinds: 0 conv3x3 (fused GN+SiLU+conv implicit GEMM), 1 conv1x1 (skip / qkv / proj), 2 attention core,
+ * 3 GroupNorm statistics, 4 other.  drm_profile_collect synchronises the recorded events and returns totals since
+ * the last drm_profile_reset: each array has DRM_PROFILE_KINDS entries. */
+#define DRM_PROFILE_KINDS 5
+void drm_profile_enable(int on);
+void drm_profile_reset(void);
+int drm_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches);
 
 /* Standard-normal fill from the library's Philox4x32-10 stream (throughput mode noise source). */
 int drm_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
