@@ -132,7 +132,11 @@ def cpu_baseline(args):
     from oracle import unet as ou
 
     H, W = args.height, args.width
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 32))  # more intra-op threads than that only slow oneDNN down at batch 1
     torch.set_num_threads(threads)
     Pi = synth.synth_state_dict(ou.param_manifest(ou.ILLNET_CFG, "unet"), synth.SEED_ILLNET)
     Pr = synth.synth_state_dict(ou.param_manifest(ou.REFNET_CFG, "encoder"), synth.SEED_REFNET)
@@ -148,9 +152,12 @@ def cpu_baseline(args):
         zk, _ = osamp.brdf_schedule(z, z0, 0.95, i)
         return Lr + ou.unet_forward(Pi, ti, xc, t_emb=ou.z_embed(Pz, zk - z0))
 
-    one(0)  # warm-up
+    tw = time.time()
+    one(0)  # warm-up (also bounds the sample: a slow host gets fewer timed steps)
+    tw = time.time() - tw
+    budget = 15.0
     n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < 10.0 and n < 12):
+    while n < 1 or (n < 12 and (time.time() - t0) + tw < budget):
         one(n)
         n += 1
     dt = time.time() - t0
