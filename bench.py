@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+F16_MFMA_PEAK_TFLOPS = 2516.0  # dense f16/bf16 MFMA peak (v_mfma_f32_32x32x16_f16); the split path issues 3 MFMA FLOPs per algorithmic FLOP
 # algorithmic matmul GFLOP per sample per forward (measured from the reference modules)
 GFLOP = {"illnet": {(128, 128): 202.66, (128, 256): 406.76}, "refnet": {(128, 128): 34.83, (128, 256): 70.10},
          "obsnet": {(128, 128): 215.34, (128, 256): 448.24}}
@@ -46,12 +47,14 @@ def parse():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
+                    help="conv arithmetic: exact fp32 MFMA, or split fp16 hi/lo x3 MFMA with fp32 accumulate (fp32-accurate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
 
 
-def build_models(workload, dev):
+def build_models(workload, dev, precision="fp32"):
     from drmnet_amd import synth
     from drmnet_amd.config import instantiate_from_config, load_config
 
@@ -64,12 +67,15 @@ def build_models(workload, dev):
         synth.load_synth(m.refnet_model.diffusion_model, synth.SEED_REFNET)
         m.illnet_model.z_emb_layer.load_state_dict(synth.synth_state_dict(
             [(k, tuple(v.shape)) for k, v in m.illnet_model.z_emb_layer.state_dict().items()], synth.SEED_ZEMB))
+        m.illnet_model.diffusion_model.set_precision(precision)
+        m.refnet_model.diffusion_model.set_precision(precision)
         return m.to(dev)
     cfg = load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["model"]
     cfg["params"].pop("ckpt_path")
     cfg["params"]["use_ema"] = False
     m = instantiate_from_config(cfg)
     synth.load_synth(m.model.diffusion_model, synth.SEED_OBSNET)
+    m.model.diffusion_model.set_precision(precision)
     return m.to(dev)
 
 
@@ -189,7 +195,7 @@ def main():
     from drmnet_amd import _lib
 
     L = _lib.lib()
-    model = build_models(args.workload, dev)
+    model = build_models(args.workload, dev, args.precision)
     step, gflop, desc = make_step(args, model, dev)
 
     def barrier():
@@ -227,8 +233,13 @@ def main():
                                 "algorithmic_GBps": round(by[k] / ms[k] / 1e6, 1) if ms[k] > 0 else None} for k in range(K) if n[k] > 0}
         if n[0] > 0:
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp32 v_mfma_f32_32x32x2_f32)",
-                        "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            split = args.precision == "f16x3"
+            peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            kname = ("conv_igemm_split_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp16 hi/lo x3 v_mfma_f32_32x32x16_f16, fp32 accumulate; "
+                     "achieved counts ALGORITHMIC FLOPs, the matrix cores execute 3x that)") if split else \
+                "conv_igemm_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp32 v_mfma_f32_32x32x2_f32)"
+            roofline = {"bound": "mfma", "kernel": kname,
+                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": None, "launches": int(n[0]), "avg_launch_ms": round(ms[0] / n[0], 4),
                         "flops_per_launch": round(fl[0] / n[0], 1), "share_of_step_time": round(ms[0] * 1e-3 / dt, 3)}
 
@@ -246,7 +257,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "fp32" else "f32 via split f16x3 MFMA (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": args.batch, "refmap": f"3x{args.height}x{args.width}",
                        "weights": "seeded synthetic (no checkpoint offline)", "parallelism": f"batch-sharded x{world}, no collective",

@@ -71,6 +71,15 @@ int with_scratch(hipStream_t s, Body&& body) {
   return DRM_OK;
 }
 
+int g_op_precision = PREC_FP32;  // arithmetic used by the drm_op_* entry points (drm_set_op_precision)
+
+// packs one conv weight for the current op precision; `slot` = 64-float scale slot (2^k, 2^-k), `scratch` = 1 uint
+int pack_for_ops(const float* w, float* dst, float* slot, float* scratch, int cout, int cin, int taps, int coutp, int cinp, hipStream_t s) {
+  if (g_op_precision == PREC_F16X3 && cinp % 32 == 0)
+    return launch_pack_conv_weight_split(w, dst, slot, reinterpret_cast<unsigned*>(scratch), cout, cin, taps, coutp, cinp, s);
+  return launch_pack_conv_weight(w, dst, cout, cin, taps, coutp, cinp, s);
+}
+
 size_t unet_ws(UNet& net, int N, int H, int W) {
   Arena a;
   a.dry = true;
@@ -165,8 +174,10 @@ int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, 
     DRM_REQUIRE((!residual && !emb) || Cout == coutp, "residual/emb need Cout % 32 == 0");
     const size_t hw = (size_t)H * W;
     return with_scratch(s, [&](Arena& ar) -> int {
-      Ctx c{&ar, s, N};
+      Ctx c{&ar, s, N, g_op_precision};
       Act xa = new_act(c, cinp, H, W);
+      float* wb = ar.alloc<float>(64);  // base for offsets: [0..63] = scale slot, then scratch
+      float* scratch = ar.alloc<float>(64);
       float* wp = ar.alloc<float>(packed_conv_weight_floats(taps, coutp, cinp));
       float* bp = ar.alloc<float>(coutp);
       float* sc = ar.alloc<float>((size_t)N * cinp);
@@ -179,7 +190,7 @@ int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, 
         return ensure_moments(c, xa);
       }
       DRM_TRY(launch_pack_input(x, nullptr, nullptr, xa.p, N, H, W, Cin, 0, cinp, s));
-      DRM_TRY(launch_pack_conv_weight(w, wp, Cout, Cin, taps, coutp, cinp, s));
+      DRM_TRY(pack_for_ops(w, wp, wb, scratch, Cout, Cin, taps, coutp, cinp, s));
       if (b) DRM_HIP_CHECK(hipMemcpyAsync(bp, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
       ConvArgs a;
       if (gamma) {
@@ -196,8 +207,8 @@ int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, 
       a.src0 = xa.p; a.C0 = cinp; a.N = N; a.H = H; a.W = W; a.silu = silu;
       a.w = wp; a.bias = bp; a.taps = taps; a.Cout = coutp;
       a.emb = emb; a.emb_stride = Cout;
-      a.out = out; a.out_nchw = 1; a.cout_valid = Cout;
-      return launch_conv(a, s);
+      a.out = out; a.out_nchw = 1; a.cout_valid = Cout; a.cin_real = Cin;
+      return run_conv(c, a, wb, 0);
     });
   });
 }
@@ -212,7 +223,7 @@ int drm_op_resblock(const float* x0, int C0, int up0, const float* x1, int C1, c
     DRM_REQUIRE(cin % 32 == 0 && Cout % 32 == 0 && C0 % 32 == 0, "channels % 32");
     DRM_REQUIRE(emb_dim <= 512, "emb_dim <= 512");
     return with_scratch(s, [&](Arena& ar) -> int {
-      Ctx c{&ar, s, N};
+      Ctx c{&ar, s, N, g_op_precision};
       // packed weights laid out like UNet::add_res
       ResLayer r;
       r.cin = cin; r.cout = Cout; r.has_skip = has_skip; r.emb_off = 0;
@@ -223,6 +234,7 @@ int drm_op_resblock(const float* x0, int C0, int up0, const float* x1, int C1, c
       float* n2w = ar.alloc<float>(Cout); float* n2b = ar.alloc<float>(Cout);
       float* c2w = ar.alloc<float>(packed_conv_weight_floats(9, Cout, Cout)); float* c2b = ar.alloc<float>(Cout);
       float* skw = ar.alloc<float>(packed_conv_weight_floats(1, Cout, cin)); float* skb = ar.alloc<float>(Cout);
+      float* s1 = ar.alloc<float>(64); float* s2 = ar.alloc<float>(64); float* s3 = ar.alloc<float>(64); float* scratch = ar.alloc<float>(64);
       float* e_out = ar.alloc<float>((size_t)N * Cout);
       Act a0 = new_act(c, C0, H, W);
       a0.up = up0;
@@ -231,17 +243,18 @@ int drm_op_resblock(const float* x0, int C0, int up0, const float* x1, int C1, c
       if (!ar.dry) {
         r.n1_w = off(n1w); r.n1_b = off(n1b); r.c1_w = off(c1w); r.c1_b = off(c1b); r.n2_w = off(n2w); r.n2_b = off(n2b);
         r.c2_w = off(c2w); r.c2_b = off(c2b); r.sk_w = off(skw); r.sk_b = off(skb);
+        r.c1_s = off(s1); r.c2_s = off(s2); r.sk_s = off(s3);
         auto cp = [&](float* d, const float* sp, size_t n) -> int {
           DRM_HIP_CHECK(hipMemcpyAsync(d, sp, n * sizeof(float), hipMemcpyDeviceToDevice, s));
           return DRM_OK;
         };
         DRM_TRY(cp(n1w, params[0], cin)); DRM_TRY(cp(n1b, params[1], cin));
-        DRM_TRY(launch_pack_conv_weight(params[2], c1w, Cout, cin, 9, Cout, cin, s)); DRM_TRY(cp(c1b, params[3], Cout));
+        DRM_TRY(pack_for_ops(params[2], c1w, s1, scratch, Cout, cin, 9, Cout, cin, s)); DRM_TRY(cp(c1b, params[3], Cout));
         DRM_TRY(launch_linear(emb, params[4], params[5], e_out, N, emb_dim, Cout, 1, 0, s));
         DRM_TRY(cp(n2w, params[6], Cout)); DRM_TRY(cp(n2b, params[7], Cout));
-        DRM_TRY(launch_pack_conv_weight(params[8], c2w, Cout, Cout, 9, Cout, Cout, s)); DRM_TRY(cp(c2b, params[9], Cout));
+        DRM_TRY(pack_for_ops(params[8], c2w, s2, scratch, Cout, Cout, 9, Cout, Cout, s)); DRM_TRY(cp(c2b, params[9], Cout));
         if (has_skip) {
-          DRM_TRY(launch_pack_conv_weight(params[10], skw, Cout, cin, 1, Cout, cin, s)); DRM_TRY(cp(skb, params[11], Cout));
+          DRM_TRY(pack_for_ops(params[10], skw, s3, scratch, Cout, cin, 1, Cout, cin, s)); DRM_TRY(cp(skb, params[11], Cout));
         }
         DRM_TRY(launch_nchw_to_nhwc(x0, a0.p, N, H >> up0, W >> up0, C0, s));
         if (C1 > 0) DRM_TRY(launch_nchw_to_nhwc(x1, a1.p, N, H, W, C1, s));
@@ -258,7 +271,7 @@ int drm_op_attention_block(const float* x, const float* const* params, float* ou
     hipStream_t s = static_cast<hipStream_t>(stream);
     DRM_REQUIRE(C % 32 == 0, "channels % 32");
     return with_scratch(s, [&](Arena& ar) -> int {
-      Ctx c{&ar, s, N};
+      Ctx c{&ar, s, N, g_op_precision};
       AttnLayer l;
       l.ch = C;
       float* wb = ar.alloc<float>(1);
@@ -266,15 +279,16 @@ int drm_op_attention_block(const float* x, const float* const* params, float* ou
       float* nw = ar.alloc<float>(C); float* nb = ar.alloc<float>(C);
       float* qw = ar.alloc<float>(packed_conv_weight_floats(1, 3 * C, C)); float* qb = ar.alloc<float>(3 * C);
       float* pw = ar.alloc<float>(packed_conv_weight_floats(1, C, C)); float* pb = ar.alloc<float>(C);
+      float* s1 = ar.alloc<float>(64); float* s2 = ar.alloc<float>(64); float* scratch = ar.alloc<float>(64);
       Act a = new_act(c, C, H, W);
       Act o = new_act(c, C, H, W);
       if (!ar.dry) {
-        l.n_w = off(nw); l.n_b = off(nb); l.qkv_w = off(qw); l.qkv_b = off(qb); l.proj_w = off(pw); l.proj_b = off(pb);
+        l.n_w = off(nw); l.n_b = off(nb); l.qkv_w = off(qw); l.qkv_b = off(qb); l.proj_w = off(pw); l.proj_b = off(pb); l.qkv_s = off(s1); l.proj_s = off(s2);
         DRM_HIP_CHECK(hipMemcpyAsync(nw, params[0], C * sizeof(float), hipMemcpyDeviceToDevice, s));
         DRM_HIP_CHECK(hipMemcpyAsync(nb, params[1], C * sizeof(float), hipMemcpyDeviceToDevice, s));
-        DRM_TRY(launch_pack_conv_weight(params[2], qw, 3 * C, C, 1, 3 * C, C, s));
+        DRM_TRY(pack_for_ops(params[2], qw, s1, scratch, 3 * C, C, 1, 3 * C, C, s));
         DRM_HIP_CHECK(hipMemcpyAsync(qb, params[3], 3 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-        DRM_TRY(launch_pack_conv_weight(params[4], pw, C, C, 1, C, C, s));
+        DRM_TRY(pack_for_ops(params[4], pw, s2, scratch, C, C, 1, C, C, s));
         DRM_HIP_CHECK(hipMemcpyAsync(pb, params[5], C * sizeof(float), hipMemcpyDeviceToDevice, s));
         DRM_TRY(launch_nchw_to_nhwc(x, a.p, N, H, W, C, s));
       }
@@ -357,6 +371,21 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
     Arena ar;
     DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
     return ddpm_sample(&net->net, x, pred_x0, cond, coef, T_start, clip_denoised, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream));
+  });
+}
+
+int drm_unet_set_precision(drm_unet* net, int precision) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && (precision == PREC_FP32 || precision == PREC_F16X3), "precision must be 0 (fp32 MFMA) or 1 (split fp16 x3)");
+    net->net.precision = precision;
+    return DRM_OK;
+  });
+}
+int drm_set_op_precision(int precision) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(precision == PREC_FP32 || precision == PREC_F16X3, "precision must be 0 (fp32 MFMA) or 1 (split fp16 x3)");
+    g_op_precision = precision;
+    return DRM_OK;
   });
 }
 

@@ -65,8 +65,15 @@ struct ConvArgs {
   float* out = nullptr;             // NHWC [N,H,W,Cout], or NCHW [N,cout_valid,H,W] if out_nchw
   int out_nchw = 0, cout_valid = 0;
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
+  const float* w_inv_scale = nullptr;  // split-precision path: device scalar 2^-k undoing the weight pre-scaling
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
+// split-precision (fp16 hi/lo x 3 MFMA, fp32-accurate) variant; a.w = pre-split weights (conv_split.hip)
+int launch_conv_split(const ConvArgs& a, hipStream_t s);
+size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);
+int launch_pack_conv_weight_split(const float* w, float* packed, float* scales, unsigned* scratch, int Cout, int Cin, int taps, int CoutP,
+                                  int CinP, hipStream_t s);
+enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1 };
 // repack PyTorch conv weight [Cout][Cin][kh][kw] -> [taps][CinP/4][CoutP][4] (zero padded)
 int launch_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int taps, int CoutP, int CinP, hipStream_t s);
 size_t packed_conv_weight_floats(int taps, int CoutP, int CinP);

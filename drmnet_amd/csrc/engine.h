@@ -51,17 +51,19 @@ struct ParamSlot {
   size_t dst = 0;          // float offset into the packed weight buffer
   size_t count = 0;        // floats copied (PK_COPY)
   int cout = 0, cin = 0, taps = 0, coutp = 0, cinp = 0;  // PK_CONV
+  size_t scale_dst = 0;    // PK_CONV: 2 floats (2^k, 2^-k) of the split-precision weight pre-scaling
 };
 
 struct ResLayer {
   int cin = 0, cout = 0;
   size_t n1_w = 0, n1_b = 0, c1_w = 0, c1_b = 0, n2_w = 0, n2_b = 0, c2_w = 0, c2_b = 0, sk_w = 0, sk_b = 0;
+  size_t c1_s = 0, c2_s = 0, sk_s = 0;  // weight pre-scaling slots (split-precision path)
   int emb_off = 0;  // column offset of this block's emb_layers output in the fused embedding buffer
   bool has_skip = false;
 };
 struct AttnLayer {
   int ch = 0;
-  size_t n_w = 0, n_b = 0, qkv_w = 0, qkv_b = 0, proj_w = 0, proj_b = 0;
+  size_t n_w = 0, n_b = 0, qkv_w = 0, qkv_b = 0, proj_w = 0, proj_b = 0, qkv_s = 0, proj_s = 0;
 };
 struct Layer {
   enum Kind { RES, ATTN, DOWN, UP } kind;
@@ -77,10 +79,12 @@ class UNet {
   std::vector<Layer> middle;
   int final_ch = 0, emb_dim = 0, emb_total = 0, in_cp = 0, out_cp = 0;
   // packed-buffer offsets
-  size_t te0_w = 0, te0_b = 0, te2_w = 0, te2_b = 0, stem_w = 0, stem_b = 0, embcat_w = 0, embcat_b = 0, on_w = 0, on_b = 0, oc_w = 0, oc_b = 0;
+  size_t te0_w = 0, te0_b = 0, te2_w = 0, te2_b = 0, stem_w = 0, stem_b = 0, embcat_w = 0, embcat_b = 0, on_w = 0, on_b = 0, oc_w = 0, oc_b = 0, oc_s = 0, scratch_off = 0;
   size_t wbuf_floats = 0;
   float* wbuf = nullptr;  // device
   bool loaded = false;
+  int precision = PREC_FP32;         // arithmetic of the conv kernels: PREC_FP32 (v_mfma_f32_32x32x2_f32) or PREC_F16X3 (split fp16)
+  int loaded_precision = -1;
 
   int build(const drm_unet_desc& d);
   int load(const float* const* ptrs, int count, hipStream_t s);
@@ -90,7 +94,7 @@ class UNet {
 
  private:
   size_t add_copy(const std::string& name, std::vector<int64_t> shape, size_t padded_count = 0);
-  size_t add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d = false);
+  size_t add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d = false, size_t* scale_off = nullptr);
   void add_res(Layer& l, const std::string& prefix, int cin, int cout);
   void add_attn(Layer& l, const std::string& prefix, int ch);
 };
@@ -100,11 +104,15 @@ struct Ctx {
   Arena* ar;
   hipStream_t s;
   int N;
+  int precision = PREC_FP32;
   bool dry() const { return ar->dry; }
+  bool split() const { return precision == PREC_F16X3; }
 };
 Act new_act(Ctx& c, int C, int H, int W);
 int ensure_moments(Ctx& c, Act& a);
 int run_resblock(Ctx& c, const float* wbuf, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out);
 int run_attention(Ctx& c, const float* wbuf, const AttnLayer& a, Act& x, Act& out);
+// dispatches to the fp32 or the split-precision conv kernel; scale_off = the conv's pre-scaling slot in wbuf
+int run_conv(Ctx& c, ConvArgs& a, const float* wbuf, size_t scale_off);
 
 }  // namespace drm

@@ -38,7 +38,7 @@ size_t UNet::add_copy(const std::string& name, std::vector<int64_t> shape, size_
   return p.dst;
 }
 
-size_t UNet::add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d) {
+size_t UNet::add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d, size_t* scale_off) {
   ParamSlot p;
   p.name = name;
   if (conv1d) p.shape = {cout, cin, k};
@@ -47,6 +47,9 @@ size_t UNet::add_conv(const std::string& name, int cout, int cin, int k, int cou
   p.cout = cout; p.cin = cin; p.taps = conv1d ? k : k * k; p.coutp = coutp; p.cinp = cinp;
   p.dst = wbuf_floats;
   wbuf_floats += (packed_conv_weight_floats(p.taps, coutp, cinp) + 63) & ~size_t(63);
+  p.scale_dst = wbuf_floats;
+  wbuf_floats += 64;
+  if (scale_off) *scale_off = p.scale_dst;
   params.push_back(p);
   return p.dst;
 }
@@ -57,7 +60,7 @@ void UNet::add_res(Layer& l, const std::string& px, int cin, int cout) {
   r.cin = cin; r.cout = cout; r.has_skip = (cin != cout);
   r.n1_w = add_copy(px + ".in_layers.0.weight", {cin});
   r.n1_b = add_copy(px + ".in_layers.0.bias", {cin});
-  r.c1_w = add_conv(px + ".in_layers.2.weight", cout, cin, 3, cout, cin);
+  r.c1_w = add_conv(px + ".in_layers.2.weight", cout, cin, 3, cout, cin, false, &r.c1_s);
   r.c1_b = add_copy(px + ".in_layers.2.bias", {cout});
   r.emb_off = emb_total;
   emb_total += cout;
@@ -68,10 +71,10 @@ void UNet::add_res(Layer& l, const std::string& px, int cin, int cout) {
   params.push_back(eb);
   r.n2_w = add_copy(px + ".out_layers.0.weight", {cout});
   r.n2_b = add_copy(px + ".out_layers.0.bias", {cout});
-  r.c2_w = add_conv(px + ".out_layers.3.weight", cout, cout, 3, cout, cout);
+  r.c2_w = add_conv(px + ".out_layers.3.weight", cout, cout, 3, cout, cout, false, &r.c2_s);
   r.c2_b = add_copy(px + ".out_layers.3.bias", {cout});
   if (r.has_skip) {
-    r.sk_w = add_conv(px + ".skip_connection.weight", cout, cin, 1, cout, cin);
+    r.sk_w = add_conv(px + ".skip_connection.weight", cout, cin, 1, cout, cin, false, &r.sk_s);
     r.sk_b = add_copy(px + ".skip_connection.bias", {cout});
   }
 }
@@ -82,9 +85,9 @@ void UNet::add_attn(Layer& l, const std::string& px, int ch) {
   a.ch = ch;
   a.n_w = add_copy(px + ".norm.weight", {ch});
   a.n_b = add_copy(px + ".norm.bias", {ch});
-  a.qkv_w = add_conv(px + ".qkv.weight", 3 * ch, ch, 1, 3 * ch, ch, true);
+  a.qkv_w = add_conv(px + ".qkv.weight", 3 * ch, ch, 1, 3 * ch, ch, true, &a.qkv_s);
   a.qkv_b = add_copy(px + ".qkv.bias", {3 * ch});
-  a.proj_w = add_conv(px + ".proj_out.weight", ch, ch, 1, ch, ch, true);
+  a.proj_w = add_conv(px + ".proj_out.weight", ch, ch, 1, ch, ch, true, &a.proj_s);
   a.proj_b = add_copy(px + ".proj_out.bias", {ch});
 }
 
@@ -175,12 +178,14 @@ int UNet::build(const drm_unet_desc& d) {
   on_b = add_copy("out.0.bias", {ch});
   if (d.kind == 0) {
     DRM_REQUIRE(ch == mc, "UNetModel head expects model_channels inputs");
-    oc_w = add_conv("out.2.weight", d.out_channels, mc, 3, out_cp, mc);
+    oc_w = add_conv("out.2.weight", d.out_channels, mc, 3, out_cp, mc, false, &oc_s);
     oc_b = add_copy("out.2.bias", {d.out_channels}, out_cp);
   } else {
     oc_w = add_copy("out.3.weight", {d.out_channels, ch, 1, 1});
     oc_b = add_copy("out.3.bias", {d.out_channels});
   }
+  scratch_off = wbuf_floats;
+  wbuf_floats += 64;
   // fused embedding projection
   embcat_w = wbuf_floats;
   wbuf_floats += ((size_t)emb_total * emb_dim + 63) & ~size_t(63);
@@ -202,11 +207,15 @@ int UNet::load(const float* const* ptrs, int count, hipStream_t s) {
     DRM_REQUIRE(ptrs[i] != nullptr, "null parameter pointer for " + p.name);
     if (p.kind == PK_COPY) {
       DRM_HIP_CHECK(hipMemcpyAsync(wbuf + p.dst, ptrs[i], p.count * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else if (precision == PREC_F16X3 && p.cinp % 32 == 0) {
+      DRM_TRY(launch_pack_conv_weight_split(ptrs[i], wbuf + p.dst, wbuf + p.scale_dst, reinterpret_cast<unsigned*>(wbuf + scratch_off), p.cout,
+                                            p.cin, p.taps, p.coutp, p.cinp, s));
     } else {
       DRM_TRY(launch_pack_conv_weight(ptrs[i], wbuf + p.dst, p.cout, p.cin, p.taps, p.coutp, p.cinp, s));
     }
   }
   loaded = true;
+  loaded_precision = precision;
   return DRM_OK;
 }
 
@@ -232,6 +241,14 @@ int ensure_moments(Ctx& c, Act& a) {
   return DRM_OK;
 }
 
+int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off) {
+  if (c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0) {
+    a.w_inv_scale = Wb + scale_off + 1;
+    return launch_conv_split(a, c.s);
+  }
+  return launch_conv(a, c.s);
+}
+
 int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out) {
   const int H = x0.H, W = x0.W;
   const int C0 = x0.C, C1 = x1 ? x1->C : 0;
@@ -255,7 +272,7 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
     a.w = Wb + r.c1_w; a.bias = Wb + r.c1_b; a.taps = 9; a.Cout = r.cout;
     a.emb = emb_all ? emb_all + r.emb_off : nullptr; a.emb_stride = emb_stride;
     a.out = h1.p;
-    DRM_TRY(launch_conv(a, c.s));
+    DRM_TRY(run_conv(c, a, Wb, r.c1_s));
   }
   DRM_TRY(ensure_moments(c, h1));
   if (!c.dry()) {
@@ -267,7 +284,7 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
       k.N = c.N; k.H = H; k.W = W;
       k.w = Wb + r.sk_w; k.bias = Wb + r.sk_b; k.taps = 1; k.Cout = r.cout;
       k.out = out.p;
-      DRM_TRY(launch_conv(k, c.s));
+      DRM_TRY(run_conv(c, k, Wb, r.sk_s));
       res = out.p;
     }
     ConvArgs b;
@@ -275,7 +292,7 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
     b.gn_scale = sc2; b.gn_shift = sh2; b.silu = 1;
     b.w = Wb + r.c2_w; b.bias = Wb + r.c2_b; b.taps = 9; b.Cout = r.cout;
     b.res = res; b.out = out.p;
-    DRM_TRY(launch_conv(b, c.s));
+    DRM_TRY(run_conv(c, b, Wb, r.c2_s));
   }
   c.ar->release(mark);
   return DRM_OK;
@@ -297,12 +314,12 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
     a.src0 = x.p; a.C0 = C; a.N = c.N; a.H = H; a.W = W;
     a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
     a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.taps = 1; a.Cout = 3 * C; a.out = qkv;
-    DRM_TRY(launch_conv(a, c.s));
+    DRM_TRY(run_conv(c, a, Wb, l.qkv_s));
     DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s));
     ConvArgs p;
     p.src0 = att; p.C0 = C; p.N = c.N; p.H = H; p.W = W;
     p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.taps = 1; p.Cout = C; p.res = x.p; p.out = out.p;
-    DRM_TRY(launch_conv(p, c.s));
+    DRM_TRY(run_conv(c, p, Wb, l.proj_s));
   }
   c.ar->release(mark);
   return DRM_OK;
@@ -323,7 +340,8 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
     if (desc.kind == 0) DRM_REQUIRE(n_t == 1, "timesteps and t_emb cannot be specified at the same time");
     else DRM_REQUIRE(n_t == 1 && t_emb == nullptr, "EncoderUNetModel takes timesteps");
   }
-  Ctx c{&ar, s, N};
+  DRM_REQUIRE(ar.dry || loaded_precision == precision, "precision changed after drm_unet_load_params: reload the parameters");
+  Ctx c{&ar, s, N, precision};
   const float* Wb = wbuf;
   const int mc = desc.model_channels;
 
@@ -409,7 +427,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
       a.gn_scale = sc; a.gn_shift = sh; a.silu = 1;
       a.w = Wb + oc_w; a.bias = Wb + oc_b; a.taps = 9; a.Cout = out_cp;
       a.out = out; a.out_nchw = 1; a.cout_valid = desc.out_channels;
-      DRM_TRY(launch_conv(a, s));
+      DRM_TRY(run_conv(c, a, Wb, oc_s));
     } else {
       DRM_TRY(launch_encoder_head(h->p, sc, sh, Wb + oc_w, Wb + oc_b, out, N, h->H * h->W, final_ch, desc.out_channels, s));
     }

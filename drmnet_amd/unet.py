@@ -101,6 +101,7 @@ class _HipUNetBase(nn.Module):
         self._h = h
         self._ws = _lib.Workspace()
         self._loaded_sig = None
+        self.precision = "fp32"
         # parameter table straight from the engine == reference state_dict() order
         n = L.drm_unet_param_count(h)
         self._keys: List[str] = []
@@ -132,6 +133,20 @@ class _HipUNetBase(nn.Module):
                 pass
             self._h = None
 
+    # ------------------------------------------------------------------ arithmetic mode
+    PRECISIONS = {"fp32": 0, "f16x3": 1}
+
+    def set_precision(self, precision: str) -> "._HipUNetBase":
+        """"fp32": exact fp32 products on v_mfma_f32_32x32x2_f32 (default).
+        "f16x3": fp32 operands split into fp16 hi+lo, 3 MFMAs per product, fp32 accumulation (fp32-level accuracy,
+        16/3 x the fp32 matrix rate).  Weights are re-packed on the next forward."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {list(self.PRECISIONS)}")
+        _lib.check(_lib.lib().drm_unet_set_precision(self._h, self.PRECISIONS[precision]))
+        self.precision = precision
+        self._loaded_sig = None
+        return self
+
     # ------------------------------------------------------------------ weights
     def param_tensors(self) -> List[torch.Tensor]:
         sd = dict(self.named_parameters())
@@ -140,7 +155,7 @@ class _HipUNetBase(nn.Module):
     def sync_weights(self, force: bool = False) -> None:
         """(Re)upload parameters to the engine when they changed (load_state_dict, ema_scope swap, .to(device))."""
         ps = self.param_tensors()
-        sig = tuple((p.data_ptr(), p._version) for p in ps)
+        sig = (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)
         if not force and sig == self._loaded_sig:
             return
         dev = ps[0].device

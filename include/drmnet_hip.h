@@ -61,6 +61,17 @@ int drm_unet_param_info(const drm_unet* net, int index, char* name, int name_cap
  * EMA tensors when sampling under ema_scope. May be called again to swap weights. */
 int drm_unet_load_params(drm_unet* net, const float* const* ptrs, int count, void* stream);
 
+/* Arithmetic of the convolution / projection kernels:
+ *   0 = DRM_PREC_FP32 : v_mfma_f32_32x32x2_f32, exact fp32 products (default)
+ *   1 = DRM_PREC_F16X3: every fp32 operand split into fp16 hi + lo, products evaluated as hi*hi + hi*lo + lo*hi on the f16
+ *       matrix cores with fp32 accumulation (22-bit operands: fp32-level accuracy at 16/3 x the fp32 matrix rate).
+ * Must be set before drm_unet_load_params (weights are pre-split at load time); drm_set_op_precision does the same for the
+ * drm_op_* entry points. */
+#define DRM_PREC_FP32 0
+#define DRM_PREC_F16X3 1
+int drm_unet_set_precision(drm_unet* net, int precision);
+int drm_set_op_precision(int precision);
+
 /* Workspace (activations, statistics, attention scores) needed by one forward of batch N at HxW. */
 size_t drm_unet_workspace_bytes(const drm_unet* net, int N, int H, int W);
 

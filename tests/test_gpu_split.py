@@ -1,0 +1,122 @@
+"""GPU parity of the split-precision path ("f16x3": fp16 hi/lo x 3 MFMA, fp32 accumulate) against the same oracle and
+reference goldens as the fp32 path, at the SAME tolerances: it is an fp32-accurate evaluation, not a reduced-precision one."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import gold, rel_l2
+from drmnet_amd import synth
+from oracle import unet as ou
+from test_gpu_nets import build, full_inputs
+from test_gpu_ops import attn_manifest, block_inputs, g, resblock_manifest
+
+pytestmark = pytest.mark.gpu
+OP_TOL = 1e-5
+NET_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no fallback)"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def split_ops():
+    from drmnet_amd import ops
+
+    ops.set_precision("f16x3")
+    yield ops
+    ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize(
+    "n,cin,cout,h,w,k,norm,silu,emb,res,scale",
+    [
+        (2, 128, 128, 16, 16, 3, True, True, True, False, 1.0),
+        (3, 256, 128, 8, 8, 3, True, True, False, True, 1.0),
+        (5, 384, 64, 4, 8, 3, True, True, False, False, 1.0),
+        (9, 768, 768, 4, 4, 3, True, True, True, True, 1.0),
+        (2, 128, 3, 16, 32, 3, True, True, False, False, 1.0),
+        (2, 256, 128, 16, 16, 1, False, False, False, False, 1.0),
+        (2, 512, 1536, 8, 8, 1, True, False, False, False, 1.0),
+        (1, 32, 32, 8, 8, 3, True, True, True, True, 1.0),
+        (1, 128, 128, 128, 256, 3, True, True, True, False, 1.0),
+        (2, 128, 128, 16, 16, 1, False, False, False, False, 300.0),   # large raw activations (residual stream), no norm
+        (2, 128, 128, 16, 16, 3, False, False, False, False, 1e-3),    # tiny raw activations: lo halves in the fp16 subnormal range
+        (2, 128, 128, 16, 16, 3, True, True, False, False, 1e4),       # weights scaled far from O(1): exercised by the 2^k pre-scaling
+    ],
+)
+def test_split_norm_act_conv(dev, split_ops, n, cin, cout, h, w, k, norm, silu, emb, res, scale):
+    gen = g(100 + cin + cout + h)
+    x = torch.randn((n, cin, h, w), generator=gen) * 1.5 + 0.3
+    wt = torch.randn((cout, cin, k, k), generator=gen) / math.sqrt(cin * k * k)
+    if norm:
+        wt = wt * scale  # weight-scale case
+    else:
+        x = x * scale  # activation-scale cases
+    b = torch.randn((cout,), generator=gen) * 0.1
+    gamma = 1 + 0.1 * torch.randn((cin,), generator=gen) if norm else None
+    beta = 0.1 * torch.randn((cin,), generator=gen) if norm else None
+    e = torch.randn((n, cout), generator=gen) if emb else None
+    r = torch.randn((n, cout, h, w), generator=gen) if res else None
+    a = x
+    if norm:
+        a = F.group_norm(a, 32, gamma, beta, 1e-5)
+    if silu:
+        a = ou.silu(a)
+    ref = F.conv2d(a.double(), wt.double(), b.double(), padding=k // 2)
+    if emb:
+        ref = ref + e[:, :, None, None]
+    if res:
+        ref = ref + r
+    to = lambda t: None if t is None else t.to(dev)
+    out = split_ops.norm_act_conv(to(x), to(wt), to(b), to(gamma), to(beta), silu, to(e), to(r)).cpu()
+    err = rel_l2(out, ref)
+    print(f"split conv {cin}->{cout} {h}x{w} k{k} scale {scale:g}: rel_l2 {err:.2e}")
+    assert err < OP_TOL
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(256, 128, 16), (128, 128, 16), (1536, 768, 4)])
+def test_split_resblock_vs_reference_golden(dev, split_ops, cin, cout, hw):
+    gd = gold(f"resblock_{cin}_{cout}_{hw}")
+    x, emb = block_inputs(cin, cout, hw, hw, int(gd["n"]))
+    P = synth.synth_state_dict(resblock_manifest(cin, cout), int(gd["seed"]))
+    out = split_ops.resblock([p.to(dev) for p in P.values()], x.to(dev), emb.to(dev)).cpu()
+    err = rel_l2(out, gd["out"])
+    print(f"split resblock {cin}->{cout}@{hw}: rel_l2 {err:.2e}")
+    assert err < OP_TOL
+
+
+@pytest.mark.parametrize("ch,h,w", [(512, 16, 16), (768, 4, 8)])
+def test_split_attention_block_vs_reference_golden(dev, split_ops, ch, h, w):
+    gd = gold(f"attnblock_{ch}_{h}x{w}")
+    x, _ = block_inputs(ch, ch, h, w, int(gd["n"]))
+    P = synth.synth_state_dict(attn_manifest(ch), int(gd["seed"]))
+    out = split_ops.attention_block([p.to(dev) for p in P.values()], x.to(dev)).cpu()
+    err = rel_l2(out, gd["out"])
+    print(f"split attention {ch}@{h}x{w}: rel_l2 {err:.2e}")
+    assert err < OP_TOL
+
+
+@pytest.mark.parametrize("name,cfg,kind", [("illnet", ou.ILLNET_CFG, "unet"), ("refnet", ou.REFNET_CFG, "encoder"), ("obsnet", ou.OBSNET_CFG, "unet")])
+def test_split_full_width_nets_vs_reference_golden(dev, name, cfg, kind):
+    m = None
+    for n, h, w in ((2, 128, 128), (1, 128, 256)):
+        gd = gold(f"full_{name}_{h}x{w}")
+        if m is None:
+            m = build(cfg, kind, int(gd["seed"]), dev).set_precision("f16x3")
+        xc, t_emb = full_inputs(n, h, w)
+        t = torch.from_numpy(gd["t"]).to(dev)
+        out = m(xc.to(dev), t_emb=t_emb.to(dev)) if name == "illnet" else m(xc.to(dev), t)
+        e = rel_l2(out.cpu(), gd["out"])
+        print(f"split {name} {n}x{h}x{w}: rel_l2 {e:.2e}")
+        assert e < NET_TOL
+    # switching back re-packs the weights and reproduces the fp32 path
+    m.set_precision("fp32")
+    out32 = m(xc.to(dev), t_emb=t_emb.to(dev)) if name == "illnet" else m(xc.to(dev), t)
+    assert rel_l2(out32.cpu(), gd["out"]) < NET_TOL
+    del m
+    torch.cuda.empty_cache()
