@@ -19,6 +19,8 @@
 
 namespace drm {
 
+int launch_conv_split2(const ConvArgs& a, hipStream_t s);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -202,8 +204,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(ConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
 
-  load_A(0);
-  load_B(0, 0);
+  // De-phase the workgroups: all of them stream the SAME weight tiles, and in lockstep they would hit the same L2
+  // channels at the same time.  Each workgroup therefore starts at its own (chunk, tap) and wraps around; the sum is
+  // order independent up to fp32 re-association.
+  const int rot_t = (a.dbg & 16) ? 0 : logical % TAPS;
+  const int rot_c = (a.dbg & 16) ? 0 : (logical / TAPS) % nchunks;
+  auto tp = [&](int tap) { const int t = tap + rot_t; return t >= TAPS ? t - TAPS : t; };
+  auto cp = [&](int chunk) { const int c = chunk + rot_c; return c >= nchunks ? c - nchunks : c; };
+
+  load_A(cp(0));
+  load_B(cp(0), tp(0));
   store_A();
   store_B(0);
   __syncthreads();
@@ -214,11 +224,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(ConvArgs a) {
     for (int tap = 0; tap < TAPS; ++tap) {
       const bool last_tap = (tap == TAPS - 1);
       const bool last = last_tap && (chunk == nchunks - 1);
-      if (!last) load_B(last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
-      if (last_tap && !last) load_A(chunk + 1);
+      if (!last && !(a.dbg & 1)) load_B(cp(last_tap ? chunk + 1 : chunk), tp(last_tap ? 0 : tap + 1));
+      if (last_tap && !last && !(a.dbg & 2)) load_A(cp(chunk + 1));
 
-      const int tapoff = (TAPS == 9) ? ((tap / 3) * C::WT + (tap % 3)) : 0;
+      const int ptap = tp(tap);
+      const int tapoff = (TAPS == 9) ? ((ptap / 3) * C::WT + (ptap % 3)) : 0;
       const float4* Bc = Bs + buf * C::B_F4;
+      if (!(a.dbg & 4))
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int seg = s * 2 + h;
@@ -242,12 +254,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(ConvArgs a) {
             acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
           }
       }
-      if (!last) store_B(buf ^ 1);
-      if (last_tap && !last) {
-        __syncthreads();
+      if (!last && !(a.dbg & 1)) store_B(buf ^ 1);
+      if (last_tap && !last && !(a.dbg & 2)) {
+        if (!(a.dbg & 8)) __syncthreads();
         store_A();
       }
-      __syncthreads();
+      if (!(a.dbg & 8)) __syncthreads();
       buf ^= 1;
     }
   }
@@ -323,12 +335,24 @@ static int dispatch_split_tile(const ConvArgs& a, hipStream_t s) {
   return DRM_ERR_INVALID;
 }
 
-int launch_conv_split(const ConvArgs& a, hipStream_t s) {
+int launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("DRM_DBG");
+      dbg = e ? atoi(e) : 0;
+    }
+    a.dbg = dbg;
+  }
   const int Ctot = a.C0 + a.C1;
   DRM_REQUIRE(a.taps == 9 || a.taps == 1, "conv taps must be 9 or 1");
   DRM_REQUIRE(a.Cout % 32 == 0 && Ctot % 32 == 0 && a.C0 % 32 == 0, "split conv needs channels % 32 == 0");
   DRM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "conv shape");
   DRM_REQUIRE(!a.up0 || (a.H % 2 == 0 && a.W % 2 == 0), "upsampled source needs even output size");
+  static int v1 = -1;
+  if (v1 < 0) v1 = getenv("DRM_SPLIT_V1") ? 1 : 0;
+  if (!v1) return launch_conv_split2(a, s);  // LDS-DMA weight ring, 256-pixel tiles (conv_split2.hip)
   if (a.taps == 9) return dispatch_split_tile<9>(a, s);
   return dispatch_split_tile<1>(a, s);
 }

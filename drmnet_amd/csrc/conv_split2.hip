@@ -1,0 +1,381 @@
+// Split-precision fused GroupNorm+SiLU+conv implicit GEMM, second-generation pipeline (see conv_split.hip for the
+// arithmetic: fp16 hi/lo operands, 3 x v_mfma_f32_32x32x16_f16 per product slab, fp32 accumulate).
+//
+// conv_split.hip measured weight-stream bound: every 768-cycle tap step needed a 16-KB weight tile through
+// registers with only one tile in flight, and skipping the weight reloads doubled its speed.  This kernel
+//   * owns 256 output pixels (16x16, or 8x16x2 / 8x8x4 / 4x8x8 / 4x4x16 images) x 128 channels per 512-thread
+//     workgroup (8 wave64, one workgroup per CU): the weight bytes per FLOP are halved;
+//   * streams the weight tiles global -> LDS with LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into an R-slot
+//     ring, R-1 tiles in flight, retired with counted s_waitcnt vmcnt(N) + raw s_barrier so the prefetch spans barriers
+//     (cdna_hip_programming.md "Pipelining across barriers"); the packed weight layout is already the LDS image;
+//   * keeps the activation path of v1: halo tile read once per 32-channel chunk, GroupNorm affine + SiLU + fp16 hi/lo
+//     split applied once in registers, parked in LDS, re-read by the nine taps at shifted offsets.
+// All vector-memory operations a wave issues are unconditional (clamped addresses, zero-filled afterwards) so the
+// vmcnt bookkeeping below is exact and identical for every wave.
+#include <utility>
+
+#include "common.h"
+#include "profiler.h"
+
+namespace drm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R>
+struct S2Cfg {
+  static constexpr int KC = 32;
+  static constexpr int NW = WM * WN;  // waves
+  static constexpr int NTHR = NW * 64;
+  static constexpr int BM = WM * MT * 32;
+  static constexpr int BN = WN * NT * 32;
+  static constexpr int TN = BM / (TH * TW);
+  static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  static constexpr int HT = TH + 2 * HALO, WT = TW + 2 * HALO;
+  static constexpr int HPI = HT * WT;
+  static constexpr int HP = TN * HPI;
+  static constexpr int TPI = NTHR / TN;  // loader threads per image
+  static constexpr int OCT = 4;
+  static constexpr int A_SLOTS = (HPI * OCT + TPI - 1) / TPI;
+  static constexpr int A_F4 = 8 * HP;
+  static constexpr int B_F4 = 8 * BN;
+  static constexpr int B_PER = B_F4 / NTHR;  // LDS-DMA instructions per wave per weight tile
+  static constexpr int LDS_F4 = A_F4 + R * B_F4;
+  static constexpr int A_CNT = 2 * A_SLOTS + 4;  // ordinary VGPR loads per thread per chunk (activations + GroupNorm scale/shift)
+  static_assert(B_F4 % NTHR == 0 && B_PER >= 1, "every wave issues the same number of LDS-DMA loads per tile");
+  static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
+  static_assert(R >= 3, "ring needs >= 3 slots");
+};
+
+__device__ __forceinline__ float silu2(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
+  const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+  hi = (_Float16)c;
+  lo = (_Float16)(c - (float)hi);
+}
+union F4H8b {
+  float4 f4;
+  f16x8 h8;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1 KiB).
+// Issued from inline asm on purpose: hipcc then does not know an LDS write is pending and does not drain vmcnt(0)
+// before every ds_read of the loop (it does when the __builtin_amdgcn_global_load_lds form is used next to LDS reads of
+// the same array); completion is tracked by the counted waits below.  M0 carries the LDS base and is restored
+// (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <int... I, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv_split2_kernel(ConvArgs a) {
+  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R>;
+  extern __shared__ float4 lds[];
+  float4* As = lds;            // [hl 2][s 2][h 2][HP]  16-byte entries
+  float4* Bs = lds + C::A_F4;  // R x [hl 2][s 2][h 2][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  const int n_tiles = a.Cout / C::BN;
+  int logical;
+  {
+    const int id = blockIdx.x, nwg = gridDim.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+    logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+  }
+  const int n_tile = logical % n_tiles;
+  int m_tile = logical / n_tiles;
+  const int tx = m_tile % tiles_x;
+  m_tile /= tiles_x;
+  const int ty = m_tile % tiles_y;
+  const int n0 = (m_tile / tiles_y) * C::TN;
+  const int ty0 = ty * TH, tx0 = tx * TW, co0 = n_tile * C::BN;
+
+  const int Ctot = a.C0 + a.C1;
+  const int nchunks = Ctot / C::KC;
+  const int T = nchunks * TAPS;  // weight tiles == pipeline steps
+  const bool has_gn = a.gn_scale != nullptr;
+
+  // ---- activation loader (ordinary loads, always issued: addresses are clamped, invalid slots zeroed at store time)
+  const int l_img = tid / C::TPI;
+  const int l_n = n0 + l_img;
+  const int l_nc = l_n < a.N ? l_n : a.N - 1;
+  const int l_tid = tid % C::TPI;
+  const int l_o = tid % C::OCT;
+  float4 areg[C::A_SLOTS][2];
+  float4 sc[2], sh[2];
+  unsigned avalid = 0;
+
+  auto load_A = [&](int chunk) {
+    const int c = chunk * C::KC;
+    const float* src;
+    int Cs, coff, up;
+    if (c < a.C0) {
+      src = a.src0; Cs = a.C0; coff = c; up = a.up0;
+    } else {
+      src = a.src1; Cs = a.C1; coff = c - a.C0; up = 0;
+    }
+    const int Hs = up ? (a.H >> 1) : a.H, Ws = up ? (a.W >> 1) : a.W;
+    avalid = 0;
+#pragma unroll
+    for (int j = 0; j < C::A_SLOTS; ++j) {
+      const int lidx = l_tid + C::TPI * j;
+      const int hpl = lidx / C::OCT;
+      const int hy = hpl / C::WT, hx = hpl % C::WT;
+      const int y = ty0 + hy - C::HALO, x = tx0 + hx - C::HALO;
+      const bool ok = (lidx < C::HPI * C::OCT) && (l_n < a.N) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+      const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
+      const int ys = up ? (yc >> 1) : yc, xs = up ? (xc >> 1) : xc;
+      const size_t pix = ((size_t)l_nc * Hs + ys) * Ws + xs;
+      const float4* p = reinterpret_cast<const float4*>(src + pix * Cs + coff + 8 * l_o);
+      areg[j][0] = p[0];
+      areg[j][1] = p[1];
+      if (ok) avalid |= 1u << j;
+    }
+    {  // always 4 loads (a harmless re-read of the input when there is no GroupNorm) so every chunk issues A_CNT loads
+      const float* gs = has_gn ? a.gn_scale + (size_t)l_nc * Ctot + c + 8 * l_o : a.src0;
+      const float* gb = has_gn ? a.gn_shift + (size_t)l_nc * Ctot + c + 8 * l_o : a.src0;
+      const float4* ps = reinterpret_cast<const float4*>(gs);
+      const float4* pb = reinterpret_cast<const float4*>(gb);
+      sc[0] = ps[0]; sc[1] = ps[1]; sh[0] = pb[0]; sh[1] = pb[1];
+    }
+  };
+  auto store_A = [&]() {
+#pragma unroll
+    for (int j = 0; j < C::A_SLOTS; ++j) {
+      const int lidx = l_tid + C::TPI * j;
+      if (lidx < C::HPI * C::OCT) {
+        F4H8b hi, lo;
+        float v[8] = {areg[j][0].x, areg[j][0].y, areg[j][0].z, areg[j][0].w, areg[j][1].x, areg[j][1].y, areg[j][1].z, areg[j][1].w};
+        if (has_gn) {
+          const float s8[8] = {sc[0].x, sc[0].y, sc[0].z, sc[0].w, sc[1].x, sc[1].y, sc[1].z, sc[1].w};
+          const float b8[8] = {sh[0].x, sh[0].y, sh[0].z, sh[0].w, sh[1].x, sh[1].y, sh[1].z, sh[1].w};
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = v[k] * s8[k] + b8[k];
+        }
+        if (a.silu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = silu2(v[k]);
+        }
+        const bool ok = (avalid >> j) & 1u;  // conv zero padding applies after norm + activation
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          _Float16 hh, ll;
+          split2(ok ? v[k] : 0.f, hh, ll);
+          hi.h8[k] = hh;
+          lo.h8[k] = ll;
+        }
+        const int pixel = l_img * C::HPI + lidx / C::OCT;
+        As[l_o * C::HP + pixel] = hi.f4;
+        As[(4 + l_o) * C::HP + pixel] = lo.f4;
+      }
+    }
+  };
+  // ---- weight tiles: LDS-DMA, B_PER x 1 KiB per wave per tile; LDS image == packed global layout
+  const unsigned lds_bs = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Bs));  // LDS byte offset of the ring
+  auto issue_B = [&](int t) {
+    if (t >= T) t -= T;  // tail: keep issuing (into a slot nobody reads any more) so the vmcnt bookkeeping stays static
+    const int chunk = t / TAPS, tap = t - chunk * TAPS;
+    const int slot = t % R;
+    const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nchunks + chunk) * 8) * a.Cout + co0;
+#pragma unroll
+    for (int j = 0; j < C::B_PER; ++j) {
+      const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
+      const int idx = base + lane;
+      const int seg = idx / C::BN, co = idx % C::BN;
+      glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::B_F4 + base) * 16u);
+    }
+  };
+
+  int a_base[MT], b_base[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = (wm * MT + i) * 32 + r;
+    const int img = row / (TH * TW), py = (row / TW) % TH, px = row % TW;
+    a_base[i] = img * C::HPI + py * C::WT + px;
+  }
+#pragma unroll
+  for (int c = 0; c < NT; ++c) b_base[c] = (wn * NT + c) * 32 + r;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
+
+  // ---- prologue: R-1 weight tiles in flight, first activation tile staged
+#pragma unroll
+  for (int t = 0; t < R - 1; ++t) issue_B(t);
+  load_A(0);
+  store_A();  // the compiler's own wait for the areg loads also retires the (older) DMA tiles
+  wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // Per step t = chunk*TAPS + tap (tap is a compile-time constant, the chunk loop is the only runtime loop):
+  //   (1) issue the DMA of tile t+R-1 into the slot consumed at step t-1,
+  //   (2) at tap A_TAP request the next chunk's activations (A_CNT ordinary loads),
+  //   (3) MFMAs of tile t,
+  //   (4) counted wait: everything up to tile t+1 landed; allowed in flight = the R-2 younger tiles
+  //       (+ the activation loads while they are younger than tile t+1), then one barrier.
+  constexpr int A_TAP = (TAPS == 9) ? 6 : 0;
+  constexpr int BASE = C::B_PER * (R - 2);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const bool more = chunk + 1 < nchunks;
+    const int t0 = chunk * TAPS;
+    static_for(std::make_integer_sequence<int, TAPS>{}, [&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      constexpr bool last_tap = (tap == TAPS - 1);
+      const int t = t0 + tap;
+      issue_B(t + R - 1);
+      if (tap == A_TAP && more) load_A(chunk + 1);
+      {
+        constexpr int tapoff = (TAPS == 9) ? ((tap / 3) * C::WT + (tap % 3)) : 0;
+        const float4* Bc = Bs + (t % R) * C::B_F4;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int seg = s * 2 + h;
+          F4H8b ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            ah[i].f4 = As[seg * C::HP + a_base[i] + tapoff];
+            al[i].f4 = As[(4 + seg) * C::HP + a_base[i] + tapoff];
+          }
+#pragma unroll
+          for (int c = 0; c < NT; ++c) {
+            bh[c].f4 = Bc[seg * C::BN + b_base[c]];
+            bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+            }
+        }
+      }
+      if (last_tap) {
+        if (more) {
+          __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
+          store_A();                     // (compiler-inserted wait covers the areg loads)
+          wait_vmcnt<BASE>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      } else {
+        // the activation loads were issued right after tile (A_TAP step)+R-1: they are younger than tile t+1
+        // while tap - A_TAP <= R-2
+        constexpr bool a_younger = (tap >= A_TAP) && (tap - A_TAP <= R - 2);
+        if (a_younger && more) wait_vmcnt<BASE + C::A_CNT>();
+        else wait_vmcnt<BASE>();
+        __builtin_amdgcn_s_barrier();
+      }
+    });
+  }
+  wait_vmcnt<0>();  // drain the tail DMAs before the workgroup's LDS can be re-assigned
+
+  const float inv_scale = a.w_inv_scale ? *a.w_inv_scale : 1.0f;
+#pragma unroll
+  for (int c = 0; c < NT; ++c) {
+    const int co = co0 + (wn * NT + c) * 32 + r;
+    const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int img = row / (TH * TW), py = (row / TW) % TH, px = row % TW;
+        const int n = n0 + img;
+        if (n < a.N) {
+          const int y = ty0 + py, x = tx0 + px;
+          float v = acc[i][c][e] * inv_scale + bias;
+          if (a.emb) v += a.emb[(size_t)n * a.emb_stride + co];
+          const size_t pix = ((size_t)n * a.H + y) * a.W + x;
+          if (a.res) v += a.res[pix * a.Cout + co];
+          if (a.out_nchw) {
+            if (co < a.cout_valid) a.out[(((size_t)n * a.cout_valid + co) * a.H + y) * a.W + x] = v;
+          } else {
+            a.out[pix * a.Cout + co] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R>
+static int launch_s2(const ConvArgs& a, hipStream_t s) {
+  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R>;
+  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R>;
+  const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
+  static_assert(C::LDS_F4 * 16 <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set && lds_bytes > 48 * 1024) {
+    DRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_set = true;
+  }
+  const int groups = (a.N + C::TN - 1) / C::TN;
+  const long long blocks = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
+  DRM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid size");
+  {
+    const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
+    const double px = (double)a.N * a.H * a.W;
+    const double px_in = (double)a.N * ((a.H >> a.up0) * (a.W >> a.up0)) * a.C0 + px * a.C1;
+    ProfScope ps(TAPS == 9 ? PROF_CONV3 : PROF_CONV1, 2.0 * px * TAPS * cin * cout,
+                 4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NTHR), lds_bytes, s, a);
+  }
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
+// 256-pixel x {128, 64}-channel tiles on 8 waves (ring of 4), 128-pixel x 32-channel tiles on 4 waves
+template <int TAPS, int TH, int TW, int TH4, int TW4>
+static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
+  if (a.Cout % 128 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4>(a, s);
+  if (a.Cout % 64 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, 4>(a, s);
+  return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, 4>(a, s);
+}
+
+template <int TAPS>
+static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
+  if (a.H % 16 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 16, 16, 8, 16>(a, s);
+  if (a.H % 8 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 8, 16, 8, 16>(a, s);
+  if (a.H % 8 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 8, 8, 8, 8>(a, s);
+  if (a.H % 4 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 4, 8, 4, 8>(a, s);
+  if (a.H % 4 == 0 && a.W % 4 == 0) return dispatch_s2_bn<TAPS, 4, 4, 4, 4>(a, s);
+  set_error("conv: feature map " + std::to_string(a.H) + "x" + std::to_string(a.W) + " is not a multiple of 4x4");
+  return DRM_ERR_INVALID;
+}
+
+int launch_conv_split2(const ConvArgs& a, hipStream_t s) {
+  if (a.taps == 9) return dispatch_s2_tile<9>(a, s);
+  return dispatch_s2_tile<1>(a, s);
+}
+
+}  // namespace drm
