@@ -140,6 +140,7 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
   DRM_REQUIRE(C % 4 == 0 && T > 0 && N > 0, "attention shape");
   const float alpha = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, applied once to the dot product
   const int tb = (T + 63) / 64;
+  prof_tag(N, T, 1, C, C);
   ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C + 4.0 * T * T), s);
   hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
                      (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha);

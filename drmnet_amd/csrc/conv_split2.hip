@@ -83,7 +83,7 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 }
 
 template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv_split2_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R>;
   extern __shared__ float4 lds[];
   float4* As = lds;            // [hl 2][s 2][h 2][HP]  16-byte entries
@@ -195,9 +195,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void conv_split2_kernel
   const unsigned lds_bs = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Bs));  // LDS byte offset of the ring
   auto issue_B = [&](int t) {
-    if (t >= T) t -= T;  // tail: keep issuing (into a slot nobody reads any more) so the vmcnt bookkeeping stays static
+    const int slot = t % R;  // ring position of step t (the slot consumed at step t - R + 1)
+    while (t >= T) t -= T;   // tail: keep issuing (into a slot nobody reads any more) so the vmcnt bookkeeping stays static
     const int chunk = t / TAPS, tap = t - chunk * TAPS;
-    const int slot = t % R;
     const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nchunks + chunk) * 8) * a.Cout + co0;
 #pragma unroll
     for (int j = 0; j < C::B_PER; ++j) {
@@ -346,6 +346,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
     const double px = (double)a.N * a.H * a.W;
     const double px_in = (double)a.N * ((a.H >> a.up0) * (a.W >> a.up0)) * a.C0 + px * a.C1;
+    prof_tag(a.N, a.H, a.W, a.C0 + a.C1, a.Cout);
     ProfScope ps(TAPS == 9 ? PROF_CONV3 : PROF_CONV1, 2.0 * px * TAPS * cin * cout,
                  4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NTHR), lds_bytes, s, a);
@@ -357,8 +358,13 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
 // 256-pixel x {128, 64}-channel tiles on 8 waves (ring of 4), 128-pixel x 32-channel tiles on 4 waves
 template <int TAPS, int TH, int TW, int TH4, int TW4>
 static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
-  if (a.Cout % 128 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4>(a, s);
-  if (a.Cout % 64 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, 4>(a, s);
+  // Deep U-Net levels (4x8 .. 8x16 maps) have few GEMM rows: with 256x128 tiles they launch far fewer workgroups than
+  // the chip has CUs.  Shrink the tile (128 rows, then 64 / 32 channels) until the grid covers the 256 CUs.
+  const long long rows = (long long)a.N * a.H * a.W;
+  auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
+  if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4>(a, s);
+  if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, 4>(a, s);
+  if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, 4>(a, s);
   return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, 4>(a, s);
 }
 

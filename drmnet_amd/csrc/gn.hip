@@ -77,6 +77,7 @@ __global__ void chan_moments_reduce_kernel(const double* __restrict__ partial, i
 int launch_chan_moments(const float* x, int N, int HW, int C, double* partial, double2* mom, hipStream_t s) {
   DRM_REQUIRE(C % 4 == 0, "chan_moments: C % 4");
   const int splits = chan_moments_splits(HW, C);
+  prof_tag(N, HW, 1, C, C);
   ProfScope ps(PROF_GNSTATS, 3.0 * N * (double)HW * C, 4.0 * N * (double)HW * C, s);
   hipLaunchKernelGGL(chan_moments_partial_kernel, dim3(splits, N), dim3(64, 4), 0, s, x, HW, C, splits, partial);
   DRM_HIP_CHECK(hipGetLastError());

@@ -18,6 +18,8 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// optional shape tag (N,H,W,Cin,Cout) attached to the next ProfScope; DRM_PROF_DUMP=1 prints a per-shape table at collect
+void prof_tag(int n, int h, int w, int cin, int cout);
 void prof_enable(int on);
 bool prof_enabled();
 // synchronises the recorded events and accumulates; returns per-kind totals since the last reset

@@ -1,5 +1,10 @@
 #include "profiler.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <tuple>
 #include <vector>
 
 namespace drm {
@@ -9,7 +14,9 @@ struct Rec {
   hipEvent_t e0, e1;
   int kind;
   double flops, bytes;
+  int tag[5];
 };
+int g_tag[5] = {0, 0, 0, 0, 0};
 bool g_on = false;
 std::vector<Rec> g_pool;   // event pairs, reused after each collect
 size_t g_used = 0;
@@ -17,6 +24,9 @@ double g_ms[PROF_KINDS], g_fl[PROF_KINDS], g_by[PROF_KINDS];
 int64_t g_n[PROF_KINDS];
 }  // namespace
 
+void prof_tag(int n, int h, int w, int cin, int cout) {
+  g_tag[0] = n; g_tag[1] = h; g_tag[2] = w; g_tag[3] = cin; g_tag[4] = cout;
+}
 void prof_enable(int on) { g_on = on != 0; }
 bool prof_enabled() { return g_on; }
 
@@ -31,6 +41,8 @@ ProfScope::ProfScope(int k, double flops, double bytes, hipStream_t st) : kind(k
   g_pool[slot].kind = k;
   g_pool[slot].flops = flops;
   g_pool[slot].bytes = bytes;
+  for (int i = 0; i < 5; ++i) g_pool[slot].tag[i] = g_tag[i];
+  for (int i = 0; i < 5; ++i) g_tag[i] = 0;
   (void)hipEventRecord(g_pool[slot].e0, s);
 }
 
@@ -39,6 +51,8 @@ ProfScope::~ProfScope() {
 }
 
 void prof_collect(double ms[PROF_KINDS], double flops[PROF_KINDS], double bytes[PROF_KINDS], int64_t launches[PROF_KINDS]) {
+  static const bool dump = getenv("DRM_PROF_DUMP") != nullptr;
+  std::map<std::tuple<int, int, int, int, int, int>, std::tuple<double, double, int>> table;
   for (size_t i = 0; i < g_used; ++i) {
     Rec& r = g_pool[i];
     if (hipEventSynchronize(r.e1) != hipSuccess) continue;
@@ -48,6 +62,29 @@ void prof_collect(double ms[PROF_KINDS], double flops[PROF_KINDS], double bytes[
     g_fl[r.kind] += r.flops;
     g_by[r.kind] += r.bytes;
     g_n[r.kind] += 1;
+    if (dump) {
+      auto& e = table[std::make_tuple(r.kind, r.tag[0], r.tag[1], r.tag[2], r.tag[3], r.tag[4])];
+      std::get<0>(e) += t;
+      std::get<1>(e) += r.flops;
+      std::get<2>(e) += 1;
+    }
+  }
+  if (dump && !table.empty()) {
+    std::vector<std::pair<double, std::string>> rows;
+    double total = 0;
+    for (auto& kv : table) {
+      char buf[256];
+      const double t = std::get<0>(kv.second), f = std::get<1>(kv.second);
+      const int n = std::get<2>(kv.second);
+      snprintf(buf, sizeof buf, "kind %d N%-3d %3dx%-3d %4d->%-4d : %4d launches %9.3f ms total %8.4f ms/launch %7.1f TF", std::get<0>(kv.first),
+               std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), std::get<4>(kv.first), std::get<5>(kv.first), n, t, t / n,
+               t > 0 ? f / t / 1e9 : 0.0);
+      rows.emplace_back(t, buf);
+      total += t;
+    }
+    std::sort(rows.begin(), rows.end(), [](auto& a, auto& b) { return a.first > b.first; });
+    fprintf(stderr, "[drm profile] %zu shapes, %.3f ms total\n", rows.size(), total);
+    for (auto& r : rows) fprintf(stderr, "[drm profile] %s\n", r.second.c_str());
   }
   g_used = 0;
   for (int k = 0; k < PROF_KINDS; ++k) {
