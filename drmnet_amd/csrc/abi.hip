@@ -196,8 +196,7 @@ int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, 
       if (gamma) {
         DRM_HIP_CHECK(hipMemcpyAsync(gp, gamma, Cin * sizeof(float), hipMemcpyDeviceToDevice, s));
         DRM_HIP_CHECK(hipMemcpyAsync(bpn, beta, Cin * sizeof(float), hipMemcpyDeviceToDevice, s));
-        DRM_TRY(ensure_moments(c, xa));
-        DRM_TRY(launch_gn_finalize(xa.mom, cinp, nullptr, 0, gp, bpn, N, sc, sh, s));
+        DRM_TRY(gn_params(c, xa, nullptr, gp, bpn, sc, sh));
         a.gn_scale = sc; a.gn_shift = sh;
       }
       if (residual) {

@@ -66,11 +66,13 @@ struct ConvArgs {
   int out_nchw = 0, cout_valid = 0;
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
   int dbg = 0;                         // experiment switches (DRM_DBG env): 1 skip B reloads, 2 skip A reloads, 4 skip MFMA, 8 skip barriers
+  double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)
   const float* w_inv_scale = nullptr;  // split-precision path: device scalar 2^-k undoing the weight pre-scaling
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 // split-precision (fp16 hi/lo x 3 MFMA, fp32-accurate) variant; a.w = pre-split weights (conv_split.hip)
 int launch_conv_split(const ConvArgs& a, hipStream_t s);
+bool conv_split_fuses_stats();  // true when the active split kernel accumulates ConvArgs::stat_out in its epilogue
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);
 int launch_pack_conv_weight_split(const float* w, float* packed, float* scales, unsigned* scratch, int Cout, int Cin, int taps, int CoutP,
                                   int CinP, hipStream_t s);
@@ -84,8 +86,9 @@ size_t packed_conv_weight_floats(int taps, int CoutP, int CinP);
 int launch_chan_moments(const float* x, int N, int HW, int C, double* partial /*[N][splits][C][2]*/, double2* mom /*[N][C]*/, hipStream_t s);
 int chan_moments_splits(int HW, int C);
 // combine moments of up to two concatenated sources into per-(n,c) scale/shift (32 groups, eps 1e-5)
-int launch_gn_finalize(const double2* mom0, int C0, const double2* mom1, int C1, const float* gamma, const float* beta, int N,
-                       float* scale, float* shift, hipStream_t s);
+// inv0 / inv1: factor turning a table into per-pixel means (1 for tables of means, 1/(H*W) for tables of raw sums)
+int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* mom1, int C1, double inv1, const float* gamma,
+                       const float* beta, int N, float* scale, float* shift, hipStream_t s);
 
 // attention (attn.hip): qkv [N][T][3C] -> out [N][T][C]; scores workspace [N][T][T]
 int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s);

@@ -336,6 +336,13 @@ static int dispatch_split_tile(const ConvArgs& a, hipStream_t s) {
   return DRM_ERR_INVALID;
 }
 
+static int split_v1() {
+  static int v1 = -1;
+  if (v1 < 0) v1 = getenv("DRM_SPLIT_V1") ? 1 : 0;
+  return v1;
+}
+bool conv_split_fuses_stats() { return !split_v1() && getenv("DRM_NO_FUSED_STATS") == nullptr; }
+
 int launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   {
@@ -351,9 +358,7 @@ int launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
   DRM_REQUIRE(a.Cout % 32 == 0 && Ctot % 32 == 0 && a.C0 % 32 == 0, "split conv needs channels % 32 == 0");
   DRM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "conv shape");
   DRM_REQUIRE(!a.up0 || (a.H % 2 == 0 && a.W % 2 == 0), "upsampled source needs even output size");
-  static int v1 = -1;
-  if (v1 < 0) v1 = getenv("DRM_SPLIT_V1") ? 1 : 0;
-  if (!v1) return launch_conv_split2(a, s);  // LDS-DMA weight ring, 256-pixel tiles (conv_split2.hip)
+  if (!split_v1()) return launch_conv_split2(a, s);  // LDS-DMA weight ring, 256-pixel tiles (conv_split2.hip)
   if (a.taps == 9) return dispatch_split_tile<9>(a, s);
   return dispatch_split_tile<1>(a, s);
 }

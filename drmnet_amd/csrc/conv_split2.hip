@@ -300,16 +300,30 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   wait_vmcnt<0>();  // drain the tail DMAs before the workgroup's LDS can be re-assigned
 
   const float inv_scale = a.w_inv_scale ? *a.w_inv_scale : 1.0f;
+  // GroupNorm statistics of the output, fused into the epilogue: per (image in tile, column) sum / sum of squares are
+  // folded in LDS (fp32 partials per lane -> fp64 LDS atomics), then ONE global fp64 atomic per (image, channel, moment)
+  // per workgroup.  The activation tile in LDS is dead by now and is reused for the fold.
+  constexpr int PPI = TH * TW;  // GEMM rows per image inside the tile: 16 .. 256
+  const bool st = a.stat_out != nullptr;
+  double* lst = reinterpret_cast<double*>(lds);  // [TN][BN][2]
+  if (st) {
+    __builtin_amdgcn_s_barrier();  // every wave is done with the activation tile
+    for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) lst[k] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 #pragma unroll
   for (int c = 0; c < NT; ++c) {
-    const int co = co0 + (wn * NT + c) * 32 + r;
+    const int col = (wn * NT + c) * 32 + r;
+    const int co = co0 + col;
     const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // rows 0-15 / 16-31 of this 32-row tile (two images when PPI == 16)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int img = row / (TH * TW), py = (row / TW) % TH, px = row % TW;
+        const int img = row / PPI, py = (row / TW) % TH, px = row % TW;
         const int n = n0 + img;
         if (n < a.N) {
           const int y = ty0 + py, x = tx0 + px;
@@ -322,8 +336,39 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           } else {
             a.out[pix * a.Cout + co] = v;
           }
+          if (e < 8) {
+            s0 += v;
+            q0 += v * v;
+          } else {
+            s1 += v;
+            q1 += v * v;
+          }
         }
       }
+      if (st) {
+        const int row0 = (wm * MT + i) * 32;
+        if (PPI >= 32) {
+          s0 += s1;
+          q0 += q1;
+        }
+        double* d = lst + ((size_t)(row0 / PPI) * C::BN + col) * 2;
+        atomicAdd(d, (double)s0);
+        atomicAdd(d + 1, (double)q0);
+        if (PPI < 32) {
+          double* d2 = lst + ((size_t)((row0 + 16) / PPI) * C::BN + col) * 2;
+          atomicAdd(d2, (double)s1);
+          atomicAdd(d2 + 1, (double)q1);
+        }
+      }
+    }
+  }
+  if (st) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) {
+      const int img = k / (C::BN * 2), rem = k % (C::BN * 2);
+      const int n = n0 + img;
+      if (n < a.N) atomicAdd(reinterpret_cast<double*>(a.stat_out + (size_t)n * a.Cout + co0) + rem, lst[k]);
     }
   }
 }

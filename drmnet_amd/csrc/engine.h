@@ -40,6 +40,7 @@ struct Act {  // NHWC activation (+ cached per-channel moments for GroupNorm)
   int up = 0;               // logically nearest-x2 upsampled (consumer reads (y>>1, x>>1))
   double2* mom = nullptr;   // [N][C] (mean, mean of squares)
   bool mom_valid = false;
+  bool mom_sums = false;    // table holds raw sums over the stored pixels (fused conv-epilogue statistics) instead of means
 };
 
 enum ParamKind { PK_COPY, PK_CONV };
@@ -113,6 +114,9 @@ int ensure_moments(Ctx& c, Act& a);
 int run_resblock(Ctx& c, const float* wbuf, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out);
 int run_attention(Ctx& c, const float* wbuf, const AttnLayer& a, Act& x, Act& out);
 // dispatches to the fp32 or the split-precision conv kernel; scale_off = the conv's pre-scaling slot in wbuf
-int run_conv(Ctx& c, ConvArgs& a, const float* wbuf, size_t scale_off);
+// `stats_for` (optional): the activation this conv completes -- its GroupNorm statistics are then accumulated in the epilogue
+int run_conv(Ctx& c, ConvArgs& a, const float* wbuf, size_t scale_off, Act* stats_for = nullptr);
+// ensure_moments on both sources + gn_finalize into (scale, shift)
+int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift);
 
 }  // namespace drm

@@ -241,12 +241,26 @@ int ensure_moments(Ctx& c, Act& a) {
   return DRM_OK;
 }
 
-int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off) {
+int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_for) {
   if (c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0) {
     a.w_inv_scale = Wb + scale_off + 1;
+    if (stats_for && !a.out_nchw && conv_split_fuses_stats()) {
+      DRM_HIP_CHECK(hipMemsetAsync(stats_for->mom, 0, (size_t)c.N * stats_for->C * sizeof(double2), c.s));
+      a.stat_out = stats_for->mom;
+      stats_for->mom_valid = true;
+      stats_for->mom_sums = true;
+    }
     return launch_conv_split(a, c.s);
   }
   return launch_conv(a, c.s);
+}
+
+int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift) {
+  DRM_TRY(ensure_moments(c, x0));
+  if (x1) DRM_TRY(ensure_moments(c, *x1));
+  if (c.dry()) return DRM_OK;
+  auto inv = [](const Act& a) { return a.mom_sums ? 1.0 / ((double)(a.H >> a.up) * (a.W >> a.up)) : 1.0; };
+  return launch_gn_finalize(x0.mom, x0.C, inv(x0), x1 ? x1->mom : nullptr, x1 ? x1->C : 0, x1 ? inv(*x1) : 1.0, gamma, beta, c.N, scale, shift, c.s);
 }
 
 int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out) {
@@ -256,15 +270,13 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
   DRM_REQUIRE(!x1 || (x1->H == H && x1->W == W && !x1->up), "resblock skip tensor shape");
   DRM_REQUIRE(r.has_skip || (!x1 && !x0.up), "identity skip on a concatenated / upsampled input is not supported");
   const size_t mark = c.ar->mark();
-  DRM_TRY(ensure_moments(c, x0));
-  if (x1) DRM_TRY(ensure_moments(c, *x1));
   float* sc1 = c.ar->alloc<float>((size_t)c.N * r.cin);
   float* sh1 = c.ar->alloc<float>((size_t)c.N * r.cin);
   Act h1 = new_act(c, r.cout, H, W);
   float* sc2 = c.ar->alloc<float>((size_t)c.N * r.cout);
   float* sh2 = c.ar->alloc<float>((size_t)c.N * r.cout);
+  DRM_TRY(gn_params(c, x0, x1, Wb + r.n1_w, Wb + r.n1_b, sc1, sh1));
   if (!c.dry()) {
-    DRM_TRY(launch_gn_finalize(x0.mom, C0, x1 ? x1->mom : nullptr, C1, Wb + r.n1_w, Wb + r.n1_b, c.N, sc1, sh1, c.s));
     ConvArgs a;
     a.src0 = x0.p; a.src1 = x1 ? x1->p : nullptr; a.C0 = C0; a.C1 = C1; a.up0 = x0.up;
     a.N = c.N; a.H = H; a.W = W;
@@ -272,11 +284,10 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
     a.w = Wb + r.c1_w; a.bias = Wb + r.c1_b; a.taps = 9; a.Cout = r.cout;
     a.emb = emb_all ? emb_all + r.emb_off : nullptr; a.emb_stride = emb_stride;
     a.out = h1.p;
-    DRM_TRY(run_conv(c, a, Wb, r.c1_s));
+    DRM_TRY(run_conv(c, a, Wb, r.c1_s, &h1));
   }
-  DRM_TRY(ensure_moments(c, h1));
+  DRM_TRY(gn_params(c, h1, nullptr, Wb + r.n2_w, Wb + r.n2_b, sc2, sh2));
   if (!c.dry()) {
-    DRM_TRY(launch_gn_finalize(h1.mom, r.cout, nullptr, 0, Wb + r.n2_w, Wb + r.n2_b, c.N, sc2, sh2, c.s));
     const float* res = x0.p;
     if (r.has_skip) {
       ConvArgs k;
@@ -292,7 +303,7 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
     b.gn_scale = sc2; b.gn_shift = sh2; b.silu = 1;
     b.w = Wb + r.c2_w; b.bias = Wb + r.c2_b; b.taps = 9; b.Cout = r.cout;
     b.res = res; b.out = out.p;
-    DRM_TRY(run_conv(c, b, Wb, r.c2_s));
+    DRM_TRY(run_conv(c, b, Wb, r.c2_s, &out));
   }
   c.ar->release(mark);
   return DRM_OK;
@@ -302,14 +313,13 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   DRM_REQUIRE(!x.up && x.C == l.ch, "attention input");
   const int H = x.H, W = x.W, T = H * W, C = l.ch;
   const size_t mark = c.ar->mark();
-  DRM_TRY(ensure_moments(c, x));
   float* sc = c.ar->alloc<float>((size_t)c.N * C);
   float* sh = c.ar->alloc<float>((size_t)c.N * C);
+  DRM_TRY(gn_params(c, x, nullptr, Wb + l.n_w, Wb + l.n_b, sc, sh));
   float* qkv = c.ar->alloc<float>((size_t)c.N * T * 3 * C);
   float* scores = c.ar->alloc<float>((size_t)c.N * T * T);
   float* att = c.ar->alloc<float>((size_t)c.N * T * C);
   if (!c.dry()) {
-    DRM_TRY(launch_gn_finalize(x.mom, C, nullptr, 0, Wb + l.n_w, Wb + l.n_b, c.N, sc, sh, c.s));
     ConvArgs a;
     a.src0 = x.p; a.C0 = C; a.N = c.N; a.H = H; a.W = W;
     a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
@@ -319,7 +329,7 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
     ConvArgs p;
     p.src0 = att; p.C0 = C; p.N = c.N; p.H = H; p.W = W;
     p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.taps = 1; p.Cout = C; p.res = x.p; p.out = out.p;
-    DRM_TRY(run_conv(c, p, Wb, l.proj_s));
+    DRM_TRY(run_conv(c, p, Wb, l.proj_s, &out));
   }
   c.ar->release(mark);
   return DRM_OK;
@@ -416,11 +426,10 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
 
   // head
   DRM_REQUIRE(!h->up && h->C == final_ch, "head input");
-  DRM_TRY(ensure_moments(c, *h));
   float* sc = c.ar->alloc<float>((size_t)N * final_ch);
   float* sh = c.ar->alloc<float>((size_t)N * final_ch);
+  DRM_TRY(gn_params(c, *h, nullptr, Wb + on_w, Wb + on_b, sc, sh));
   if (!c.dry()) {
-    DRM_TRY(launch_gn_finalize(h->mom, final_ch, nullptr, 0, Wb + on_w, Wb + on_b, N, sc, sh, s));
     if (desc.kind == 0) {
       ConvArgs a;
       a.src0 = h->p; a.C0 = final_ch; a.N = N; a.H = h->H; a.W = h->W;

@@ -88,7 +88,8 @@ int launch_chan_moments(const float* x, int N, int HW, int C, double* partial, d
 }
 
 // grid N, block 256.  32 groups over the concatenated channel axis [C0 | C1].
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restrict__ mom0, int C0, const double2* __restrict__ mom1, int C1,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restrict__ mom0, int C0, double inv0,
+                                                           const double2* __restrict__ mom1, int C1, double inv1,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ float g_mean[32], g_rstd[32];
@@ -99,9 +100,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restr
     double m = 0.0, q = 0.0;
     for (int k = 0; k < cpg; ++k) {
       const int c = t * cpg + k;
-      const double2 v = (c < C0) ? mom0[(size_t)n * C0 + c] : mom1[(size_t)n * C1 + (c - C0)];
-      m += v.x;
-      q += v.y;
+      if (c < C0) {
+        const double2 v = mom0[(size_t)n * C0 + c];
+        m += v.x * inv0;
+        q += v.y * inv0;
+      } else {
+        const double2 v = mom1[(size_t)n * C1 + (c - C0)];
+        m += v.x * inv1;
+        q += v.y * inv1;
+      }
     }
     m /= cpg;
     q /= cpg;
@@ -119,10 +126,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restr
   }
 }
 
-int launch_gn_finalize(const double2* mom0, int C0, const double2* mom1, int C1, const float* gamma, const float* beta, int N, float* scale,
-                       float* shift, hipStream_t s) {
+int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* mom1, int C1, double inv1, const float* gamma,
+                       const float* beta, int N, float* scale, float* shift, hipStream_t s) {
   DRM_REQUIRE((C0 + C1) % 32 == 0, "GroupNorm32 needs channels % 32 == 0");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, mom0, C0, mom1, C1, gamma, beta, scale, shift);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, mom0, C0, inv0, mom1, C1, inv1, gamma, beta, scale, shift);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }
