@@ -312,29 +312,52 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  // Rows of a 32x32 accumulator tile held by this lane: 8g + 4h + k (g = 0..3, k = 0..3); the four k rows are four
+  // consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per (i, g).  All loads are issued
+  // unconditionally on clamped addresses (batched ahead of the math); only the stores are predicated.
 #pragma unroll
-  for (int c = 0; c < NT; ++c) {
-    const int col = (wn * NT + c) * 32 + r;
-    const int co = co0 + col;
-    const float bias = a.bias ? a.bias[co] : 0.f;
+  for (int i = 0; i < MT; ++i) {
+    size_t pixb[4];
+    int nimg[4];
+    bool okg[4];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // rows 0-15 / 16-31 of this 32-row tile (two images when PPI == 16)
+    for (int g = 0; g < 4; ++g) {
+      const int row = (wm * MT + i) * 32 + 8 * g + 4 * h;
+      const int img = row / PPI, py = (row / TW) % TH, px = row % TW;
+      const int n = n0 + img;
+      okg[g] = n < a.N;
+      nimg[g] = okg[g] ? n : a.N - 1;
+      pixb[g] = ((size_t)nimg[g] * a.H + (ty0 + py)) * a.W + (tx0 + px);
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const int col = (wn * NT + c) * 32 + r;
+      const int co = co0 + col;
+      const float bias = a.bias ? a.bias[co] : 0.f;
+      float rv[16], ev[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ev[g] = a.emb ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
+      if (a.res) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+      }
+      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // rows 0-15 / 16-31 of this tile (two images when PPI == 16)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int img = row / PPI, py = (row / TW) % TH, px = row % TW;
-        const int n = n0 + img;
-        if (n < a.N) {
-          const int y = ty0 + py, x = tx0 + px;
-          float v = acc[i][c][e] * inv_scale + bias;
-          if (a.emb) v += a.emb[(size_t)n * a.emb_stride + co];
-          const size_t pix = ((size_t)n * a.H + y) * a.W + x;
-          if (a.res) v += a.res[pix * a.Cout + co];
+        const int g = e >> 2;
+        const float v = acc[i][c][e] * inv_scale + bias + ev[g] + rv[e];
+        if (okg[g]) {
           if (a.out_nchw) {
-            if (co < a.cout_valid) a.out[(((size_t)n * a.cout_valid + co) * a.H + y) * a.W + x] = v;
+            if (co < a.cout_valid) {
+              const size_t pix = pixb[g] + (e & 3);
+              const size_t hw = (size_t)a.H * a.W;
+              a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v;
+            }
           } else {
-            a.out[pix * a.Cout + co] = v;
+            a.out[(pixb[g] + (e & 3)) * a.Cout + co] = v;
           }
           if (e < 8) {
             s0 += v;
