@@ -22,7 +22,7 @@ namespace drm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS>
 struct S2Cfg {
   static constexpr int KC = 32;
   static constexpr int NW = WM * WN;  // waves
@@ -40,11 +40,15 @@ struct S2Cfg {
   static constexpr int A_F4 = 8 * HP;
   static constexpr int B_F4 = 8 * BN;
   static constexpr int B_PER = B_F4 / NTHR;  // LDS-DMA instructions per wave per weight tile
-  static constexpr int LDS_F4 = A_F4 + R * B_F4;
+  static constexpr int NG = TAPS / TPS;      // pipeline steps ("groups" of TPS taps) per 32-channel chunk
+  static constexpr int G_PER = TPS * B_PER;  // LDS-DMA instructions per wave per group
+  static constexpr int G_F4 = TPS * B_F4;    // float4 per group in the ring
+  static constexpr int LDS_F4 = A_F4 + R * G_F4;
+  static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
   static constexpr int A_CNT = 2 * A_SLOTS + 4;  // ordinary VGPR loads per thread per chunk (activations + GroupNorm scale/shift)
   static_assert(B_F4 % NTHR == 0 && B_PER >= 1, "every wave issues the same number of LDS-DMA loads per tile");
   static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
-  static_assert(R >= 3, "ring needs >= 3 slots");
+  static_assert(R >= 2, "ring needs >= 2 slots");
 };
 
 __device__ __forceinline__ float silu2(float v) { return v / (1.0f + __expf(-v)); }
@@ -82,9 +86,9 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
   (f(std::integral_constant<int, I>{}), ...);
 }
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a) {
-  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R>;
+  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS>;
   extern __shared__ float4 lds[];
   float4* As = lds;            // [hl 2][s 2][h 2][HP]  16-byte entries
   float4* Bs = lds + C::A_F4;  // R x [hl 2][s 2][h 2][BN]
@@ -194,17 +198,22 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   // ---- weight tiles: LDS-DMA, B_PER x 1 KiB per wave per tile; LDS image == packed global layout
   const unsigned lds_bs = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Bs));  // LDS byte offset of the ring
-  auto issue_B = [&](int t) {
-    const int slot = t % R;  // ring position of step t (the slot consumed at step t - R + 1)
-    while (t >= T) t -= T;   // tail: keep issuing (into a slot nobody reads any more) so the vmcnt bookkeeping stays static
-    const int chunk = t / TAPS, tap = t - chunk * TAPS;
-    const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nchunks + chunk) * 8) * a.Cout + co0;
+  const int NGT = nchunks * C::NG;  // total groups
+  auto issue_G = [&](int G) {
+    const int slot = G % R;    // ring position of step G (the slot consumed at step G - R + 1)
+    while (G >= NGT) G -= NGT;  // tail: keep issuing (into a slot nobody reads any more) so the vmcnt bookkeeping stays static
+    const int chunk = G / C::NG, g = G - chunk * C::NG;
 #pragma unroll
-    for (int j = 0; j < C::B_PER; ++j) {
-      const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
-      const int idx = base + lane;
-      const int seg = idx / C::BN, co = idx % C::BN;
-      glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::B_F4 + base) * 16u);
+    for (int u = 0; u < TPS; ++u) {
+      const int tap = g * TPS + u;
+      const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nchunks + chunk) * 8) * a.Cout + co0;
+#pragma unroll
+      for (int j = 0; j < C::B_PER; ++j) {
+        const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
+        const int idx = base + lane;
+        const int seg = idx / C::BN, co = idx % C::BN;
+        glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
+      }
     }
   };
 
@@ -226,35 +235,41 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
 
-  // ---- prologue: R-1 weight tiles in flight, first activation tile staged
+  // ---- prologue: R-1 weight groups in flight, first activation tile staged
 #pragma unroll
-  for (int t = 0; t < R - 1; ++t) issue_B(t);
+  for (int G = 0; G < R - 1; ++G) issue_G(G);
   load_A(0);
-  store_A();  // the compiler's own wait for the areg loads also retires the (older) DMA tiles
+  store_A();  // the compiler's own wait for the areg loads also retires the (older) DMA groups
   wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // Per step t = chunk*TAPS + tap (tap is a compile-time constant, the chunk loop is the only runtime loop):
-  //   (1) issue the DMA of tile t+R-1 into the slot consumed at step t-1,
-  //   (2) at tap A_TAP request the next chunk's activations (A_CNT ordinary loads),
-  //   (3) MFMAs of tile t,
-  //   (4) counted wait: everything up to tile t+1 landed; allowed in flight = the R-2 younger tiles
-  //       (+ the activation loads while they are younger than tile t+1), then one barrier.
-  constexpr int A_TAP = (TAPS == 9) ? 6 : 0;
-  constexpr int BASE = C::B_PER * (R - 2);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const bool more = chunk + 1 < nchunks;
-    const int t0 = chunk * TAPS;
-    static_for(std::make_integer_sequence<int, TAPS>{}, [&](auto tapc) {
-      constexpr int tap = decltype(tapc)::value;
-      constexpr bool last_tap = (tap == TAPS - 1);
-      const int t = t0 + tap;
-      issue_B(t + R - 1);
-      if (tap == A_TAP && more) load_A(chunk + 1);
-      {
-        constexpr int tapoff = (TAPS == 9) ? ((tap / 3) * C::WT + (tap % 3)) : 0;
-        const float4* Bc = Bs + (t % R) * C::B_F4;
+  // Per step G = chunk*NG + g (g is a compile-time constant, the chunk loop is the only runtime loop):
+  //   (1) issue the DMA of group G+R-1 into the slot consumed at step G-1,
+  //   (2) at group A_G request the next chunk's activations (A_CNT ordinary loads),
+  //   (3) MFMAs of the TPS taps of group G,
+  //   (4) counted wait: everything up to group G+1 landed; allowed in flight = the R-2 younger groups
+  //       (+ the activation loads while they are younger than group G+1), then ONE barrier per TPS taps.
+  constexpr int A_G = (C::NG >= 3) ? C::NG - 2 : 0;
+  constexpr int BASE = C::G_PER * (R - 2);
+  const int nch_run = (a.dbg & 64) ? 1 : nchunks;  // experiment switch: run a single K chunk
+  for (int chunk = 0; chunk < nch_run; ++chunk) {
+    const bool more = chunk + 1 < nch_run;
+    const int G0 = chunk * C::NG;
+    static_for(std::make_integer_sequence<int, C::NG>{}, [&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr bool last_g = (g == C::NG - 1);
+      const int G = G0 + g;
+      issue_G(G + R - 1);
+      if (g == A_G && more) load_A(chunk + 1);
+      const float4* Bg = Bs + (G % R) * C::G_F4;
+#pragma unroll
+      for (int u = 0; u < TPS; ++u) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int tap = g * TPS + u;
+        const int tapoff = (TAPS == 9) ? ((tap / 3) * C::WT + (tap % 3)) : 0;
+        const float4* Bc = Bg + u * C::B_F4;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int seg = s * 2 + h;
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             }
         }
       }
-      if (last_tap) {
+      if (last_g) {
         if (more) {
           __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
           store_A();                     // (compiler-inserted wait covers the areg loads)
@@ -288,9 +303,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           __builtin_amdgcn_s_barrier();
         }
       } else {
-        // the activation loads were issued right after tile (A_TAP step)+R-1: they are younger than tile t+1
-        // while tap - A_TAP <= R-2
-        constexpr bool a_younger = (tap >= A_TAP) && (tap - A_TAP <= R - 2);
+        // the activation loads were issued right after group (A_G step)+R-1: they are younger than group G+1
+        // while g - A_G <= R-2
+        constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
         if (a_younger && more) wait_vmcnt<BASE + C::A_CNT>();
         else wait_vmcnt<BASE>();
         __builtin_amdgcn_s_barrier();
@@ -315,6 +330,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   // Rows of a 32x32 accumulator tile held by this lane: 8g + 4h + k (g = 0..3, k = 0..3); the four k rows are four
   // consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per (i, g).  All loads are issued
   // unconditionally on clamped addresses (batched ahead of the math); only the stores are predicated.
+  if (!(a.dbg & 32))  // experiment switch: skip the epilogue
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     size_t pixb[4];
@@ -396,10 +412,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   }
 }
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS>
 static int launch_s2(const ConvArgs& a, hipStream_t s) {
-  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R>;
-  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R>;
+  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS>;
+  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS>;
   const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
   static_assert(C::LDS_F4 * 16 <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
@@ -430,10 +446,24 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   // the chip has CUs.  Shrink the tile (128 rows, then 64 / 32 channels) until the grid covers the 256 CUs.
   const long long rows = (long long)a.N * a.H * a.W;
   auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
-  if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4>(a, s);
-  if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, 4>(a, s);
-  if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, 4>(a, s);
-  return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, 4>(a, s);
+  // 3x3: one barrier per kernel ROW (3 taps, 48 KB of weights per step, double-buffered); 1x1: one tap per step, ring of 4.
+  // The 256-row tile on 4x4 maps keeps the one-tap ring (its 16-image halo tile leaves no room for 96 KB of weights).
+  constexpr int TPS = (TAPS == 9) ? 3 : 1;
+  constexpr int RG = (TAPS == 9) ? 2 : 4;
+  constexpr bool big_ok = (TAPS == 1) || !(TH == 4 && TW == 4);
+  static const int small_tiles = getenv("DRM_S2_SMALL") ? atoi(getenv("DRM_S2_SMALL")) : 0;  // experiment switch
+  if (small_tiles && a.Cout % 128 == 0 && wgs(128, 128) >= 512) {
+    if (small_tiles == 1) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1>(a, s);  // 128x128 tiles, 4 waves, 2 WGs/CU
+    if (small_tiles == 3) return launch_s2<TAPS, TH, TW, 4, 1, 2, 2, 4, 1>(a, s);    // 256x64 tiles, 4 waves, 2 WGs/CU
+    return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 4, 1>(a, s);
+  }
+  if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) {
+    if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS>(a, s);
+    else return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4, 1>(a, s);
+  }
+  if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS>(a, s);
+  if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS>(a, s);
+  return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS>(a, s);
 }
 
 template <int TAPS>

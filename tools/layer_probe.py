@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Times ResBlocks through the op-level ABI (NHWC inside, realistic epilogues); DRM_DBG selects experiment switches."""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from drmnet_amd import _lib, ops, synth
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+ops.set_precision(prec)
+L = _lib.lib(); dev = torch.device("cuda:0")
+def man(cin, cout):
+    m = [("in_layers.0.weight", (cin,)), ("in_layers.0.bias", (cin,)), ("in_layers.2.weight", (cout, cin, 3, 3)), ("in_layers.2.bias", (cout,)),
+         ("emb_layers.1.weight", (cout, 512)), ("emb_layers.1.bias", (cout,)), ("out_layers.0.weight", (cout,)), ("out_layers.0.bias", (cout,)),
+         ("out_layers.3.weight", (cout, cout, 3, 3)), ("out_layers.3.bias", (cout,))]
+    if cin != cout: m += [("skip_connection.weight", (cout, cin, 1, 1)), ("skip_connection.bias", (cout,))]
+    return m
+for (n, cin, cout, h, w) in [(32, 128, 128, 128, 256), (32, 256, 256, 64, 128)]:
+    P = [p.to(dev) for p in synth.synth_state_dict(man(cin, cout), 1).values()]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((n, cin, h, w), generator=g).to(dev); emb = torch.randn((n, 512), generator=g).to(dev)
+    ops.resblock(P, x, emb); torch.cuda.synchronize()
+    L.drm_profile_reset(); L.drm_profile_enable(1)
+    for _ in range(3): ops.resblock(P, x, emb)
+    torch.cuda.synchronize(); L.drm_profile_enable(0)
+    K = 5; ms, fl, by, cnt = (C.c_double*K)(), (C.c_double*K)(), (C.c_double*K)(), (C.c_int64*K)()
+    L.drm_profile_collect(ms, fl, by, cnt)
+    print(f"{prec} dbg={os.environ.get('DRM_DBG','0')} resblock {cin}->{cout} @{h}x{w}: conv3x3 {ms[0]/cnt[0]:.3f} ms/launch ({fl[0]/ms[0]/1e9:.0f} TF)", flush=True)
+    del x, P; torch.cuda.empty_cache()
