@@ -6,10 +6,16 @@
 //   * owns 256 output pixels (16x16, or 8x16x2 / 8x8x4 / 4x8x8 / 4x4x16 images) x 128 channels per 512-thread
 //     workgroup (8 wave64, one workgroup per CU): the weight bytes per FLOP are halved;
 //   * streams the weight tiles global -> LDS with LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into an R-slot
-//     ring, R-1 tiles in flight, retired with counted s_waitcnt vmcnt(N) + raw s_barrier so the prefetch spans barriers
+//     ring of TPS-tap groups, retired with counted s_waitcnt vmcnt(N) + raw s_barrier so the prefetch spans barriers
 //     (cdna_hip_programming.md "Pipelining across barriers"); the packed weight layout is already the LDS image;
 //   * keeps the activation path of v1: halo tile read once per 32-channel chunk, GroupNorm affine + SiLU + fp16 hi/lo
-//     split applied once in registers, parked in LDS, re-read by the nine taps at shifted offsets.
+//     split applied once in registers, parked in LDS, re-read by the nine taps at shifted offsets;
+//   * is PERSISTENT: a workgroup walks several output tiles; the weight ring and the activation prefetch run straight
+//     across the tile boundary and the epilogue's stores (fire-and-forget) drain under the next tile's MFMAs, so the
+//     HBM write burst of the epilogue is no longer a serial phase of every workgroup (it measured 18 % of a
+//     128->128 @128x256 launch, all CUs bursting at once);
+//   * accumulates the GroupNorm statistics of its OUTPUT in the epilogue (fp32 partials per lane -> fp64 LDS atomics ->
+//     one global fp64 atomic per (image, channel, moment) per tile).
 // All vector-memory operations a wave issues are unconditional (clamped addresses, zero-filled afterwards) so the
 // vmcnt bookkeeping below is exact and identical for every wave.
 #include <utility>
@@ -43,9 +49,10 @@ struct S2Cfg {
   static constexpr int NG = TAPS / TPS;      // pipeline steps ("groups" of TPS taps) per 32-channel chunk
   static constexpr int G_PER = TPS * B_PER;  // LDS-DMA instructions per wave per group
   static constexpr int G_F4 = TPS * B_F4;    // float4 per group in the ring
-  static constexpr int LDS_F4 = A_F4 + R * G_F4;
-  static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
+  static constexpr int ST_F4 = TN * BN;      // statistics fold area: [TN][BN] x (sum, sumsq) doubles == one float4 each
+  static constexpr int LDS_F4 = A_F4 + R * G_F4 + ST_F4;
   static constexpr int A_CNT = 2 * A_SLOTS + 4;  // ordinary VGPR loads per thread per chunk (activations + GroupNorm scale/shift)
+  static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
   static_assert(B_F4 % NTHR == 0 && B_PER >= 1, "every wave issues the same number of LDS-DMA loads per tile");
   static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
   static_assert(R >= 2, "ring needs >= 2 slots");
@@ -86,12 +93,17 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
   (f(std::integral_constant<int, I>{}), ...);
 }
 
+struct TilePos {
+  int n0, ty0, tx0, co0;
+};
+
 template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS>;
   extern __shared__ float4 lds[];
-  float4* As = lds;            // [hl 2][s 2][h 2][HP]  16-byte entries
-  float4* Bs = lds + C::A_F4;  // R x [hl 2][s 2][h 2][BN]
+  float4* As = lds;                                                   // [hl 2][s 2][h 2][HP]  16-byte entries
+  float4* Bs = lds + C::A_F4;                                         // R x TPS x [hl 2][s 2][h 2][BN]
+  double* lst = reinterpret_cast<double*>(lds + C::A_F4 + R * C::G_F4);  // [TN][BN][2]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,38 +111,47 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
+  // ---- persistent tile walk.  Logical tile ids are dealt to the 8 XCDs in contiguous ranges (blocks b and b+8 share an
+  //      XCD and its L2); inside a range consecutive ids are the Cout tiles of one pixel tile, then spatial neighbours.
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
   const int n_tiles = a.Cout / C::BN;
-  int logical;
-  {
-    const int id = blockIdx.x, nwg = gridDim.x;
-    const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
-    logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
-  }
-  const int n_tile = logical % n_tiles;
-  int m_tile = logical / n_tiles;
-  const int tx = m_tile % tiles_x;
-  m_tile /= tiles_x;
-  const int ty = m_tile % tiles_y;
-  const int n0 = (m_tile / tiles_y) * C::TN;
-  const int ty0 = ty * TH, tx0 = tx * TW, co0 = n_tile * C::BN;
+  const int total = ((a.N + C::TN - 1) / C::TN) * tiles_y * tiles_x * n_tiles;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int q8 = total >> 3, r8 = total & 7;
+  const int x_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int x_count = q8 + (xcd < r8 ? 1 : 0);
+  const int J = ((int)gridDim.x - xcd + 7) >> 3;  // workgroups living on this XCD
+  auto decode = [&](int logical) {
+    TilePos t;
+    const int n_tile = logical % n_tiles;
+    int m_tile = logical / n_tiles;
+    const int tx = m_tile % tiles_x;
+    m_tile /= tiles_x;
+    const int ty = m_tile % tiles_y;
+    t.n0 = (m_tile / tiles_y) * C::TN;
+    t.ty0 = ty * TH;
+    t.tx0 = tx * TW;
+    t.co0 = n_tile * C::BN;
+    return t;
+  };
+  int k_tile = jx;  // index inside this XCD's range
+  if (k_tile >= x_count) return;
+  TilePos cur = decode(x_start + k_tile);
 
   const int Ctot = a.C0 + a.C1;
   const int nchunks = Ctot / C::KC;
-  const int T = nchunks * TAPS;  // weight tiles == pipeline steps
+  const int NGT = nchunks * C::NG;  // weight groups (pipeline steps) per tile
   const bool has_gn = a.gn_scale != nullptr;
 
   // ---- activation loader (ordinary loads, always issued: addresses are clamped, invalid slots zeroed at store time)
   const int l_img = tid / C::TPI;
-  const int l_n = n0 + l_img;
-  const int l_nc = l_n < a.N ? l_n : a.N - 1;
   const int l_tid = tid % C::TPI;
   const int l_o = tid % C::OCT;
   float4 areg[C::A_SLOTS][2];
   float4 sc[2], sh[2];
   unsigned avalid = 0;
 
-  auto load_A = [&](int chunk) {
+  auto load_A = [&](const TilePos& tp, int chunk) {
     const int c = chunk * C::KC;
     const float* src;
     int Cs, coff, up;
@@ -140,13 +161,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       src = a.src1; Cs = a.C1; coff = c - a.C0; up = 0;
     }
     const int Hs = up ? (a.H >> 1) : a.H, Ws = up ? (a.W >> 1) : a.W;
+    const int l_n = tp.n0 + l_img;
+    const int l_nc = l_n < a.N ? l_n : a.N - 1;
     avalid = 0;
 #pragma unroll
     for (int j = 0; j < C::A_SLOTS; ++j) {
       const int lidx = l_tid + C::TPI * j;
       const int hpl = lidx / C::OCT;
       const int hy = hpl / C::WT, hx = hpl % C::WT;
-      const int y = ty0 + hy - C::HALO, x = tx0 + hx - C::HALO;
+      const int y = tp.ty0 + hy - C::HALO, x = tp.tx0 + hx - C::HALO;
       const bool ok = (lidx < C::HPI * C::OCT) && (l_n < a.N) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
       const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
       const int ys = up ? (yc >> 1) : yc, xs = up ? (xc >> 1) : xc;
@@ -195,14 +218,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       }
     }
   };
-  // ---- weight tiles: LDS-DMA, B_PER x 1 KiB per wave per tile; LDS image == packed global layout
+  // ---- weight groups: LDS-DMA, G_PER x 1 KiB per wave per group; LDS image == packed global layout.
+  //      `gseq` counts groups since kernel start (ring slot = gseq % R); (g_in_tile, co0) say which weights.
   const unsigned lds_bs = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Bs));  // LDS byte offset of the ring
-  const int NGT = nchunks * C::NG;  // total groups
-  auto issue_G = [&](int G) {
-    const int slot = G % R;    // ring position of step G (the slot consumed at step G - R + 1)
-    while (G >= NGT) G -= NGT;  // tail: keep issuing (into a slot nobody reads any more) so the vmcnt bookkeeping stays static
-    const int chunk = G / C::NG, g = G - chunk * C::NG;
+  auto issue_G = [&](int gseq, int g_in_tile, int co0) {
+    const int slot = gseq % R;
+    const int chunk = g_in_tile / C::NG, g = g_in_tile - chunk * C::NG;
 #pragma unroll
     for (int u = 0; u < TPS; ++u) {
       const int tap = g * TPS + u;
@@ -235,181 +257,216 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
 
-  // ---- prologue: R-1 weight groups in flight, first activation tile staged
+  const float inv_scale = a.w_inv_scale ? *a.w_inv_scale : 1.0f;
+  constexpr int PPI = TH * TW;  // GEMM rows per image inside the tile: 16 .. 256
+  const bool st = a.stat_out != nullptr;
+  if (st) {
+    for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) lst[k] = 0.0;
+  }
+
+  // ---- prologue: R-1 weight groups in flight (they may already belong to the next tile when a tile has < R-1 groups),
+  //      first activation tile staged
+  int gseq = 0;  // groups issued so far
+  {
+    int k2 = k_tile;
+    TilePos tp = cur;
+    int gi = 0;
 #pragma unroll
-  for (int G = 0; G < R - 1; ++G) issue_G(G);
-  load_A(0);
+    for (int G = 0; G < R - 1; ++G) {
+      if (gi >= NGT) {  // spill into the following tile (or wrap on the last one: harmless duplicate)
+        gi = 0;
+        if (k2 + J < x_count) {
+          k2 += J;
+          tp = decode(x_start + k2);
+        }
+      }
+      issue_G(gseq++, gi++, tp.co0);
+    }
+  }
+  load_A(cur, 0);
   store_A();  // the compiler's own wait for the areg loads also retires the (older) DMA groups
   wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // Per step G = chunk*NG + g (g is a compile-time constant, the chunk loop is the only runtime loop):
-  //   (1) issue the DMA of group G+R-1 into the slot consumed at step G-1,
-  //   (2) at group A_G request the next chunk's activations (A_CNT ordinary loads),
-  //   (3) MFMAs of the TPS taps of group G,
-  //   (4) counted wait: everything up to group G+1 landed; allowed in flight = the R-2 younger groups
-  //       (+ the activation loads while they are younger than group G+1), then ONE barrier per TPS taps.
+  // Per step (group g of chunk c of the current tile; g is a compile-time constant):
+  //   (1) issue the DMA of the group R-1 steps ahead into the slot consumed one step ago (it may belong to the NEXT tile),
+  //   (2) at group A_G request the next chunk's activations -- or the first chunk of the next tile,
+  //   (3) MFMAs of the TPS taps of the group,
+  //   (4) counted wait: everything up to the next group landed; allowed in flight = the R-2 younger groups
+  //       (+ the activation loads while they are younger than the next group), then ONE barrier per TPS taps.
   constexpr int A_G = (C::NG >= 3) ? C::NG - 2 : 0;
   constexpr int BASE = C::G_PER * (R - 2);
-  const int nch_run = (a.dbg & 64) ? 1 : nchunks;  // experiment switch: run a single K chunk
-  for (int chunk = 0; chunk < nch_run; ++chunk) {
-    const bool more = chunk + 1 < nch_run;
-    const int G0 = chunk * C::NG;
-    static_for(std::make_integer_sequence<int, C::NG>{}, [&](auto gc) {
-      constexpr int g = decltype(gc)::value;
-      constexpr bool last_g = (g == C::NG - 1);
-      const int G = G0 + g;
-      issue_G(G + R - 1);
-      if (g == A_G && more) load_A(chunk + 1);
-      const float4* Bg = Bs + (G % R) * C::G_F4;
-#pragma unroll
-      for (int u = 0; u < TPS; ++u) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int tap = g * TPS + u;
-        const int tapoff = (TAPS == 9) ? ((tap / 3) * C::WT + (tap % 3)) : 0;
-        const float4* Bc = Bg + u * C::B_F4;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int seg = s * 2 + h;
-          F4H8b ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            ah[i].f4 = As[seg * C::HP + a_base[i] + tapoff];
-            al[i].f4 = As[(4 + seg) * C::HP + a_base[i] + tapoff];
+  int step = 0;  // steps executed so far (== gseq - (R-1))
+  while (true) {
+    const bool has_next = k_tile + J < x_count;
+    const TilePos nxt = has_next ? decode(x_start + k_tile + J) : cur;
+    const int nch_run = (a.dbg & 64) ? 1 : nchunks;  // experiment switch: run a single K chunk
+    for (int chunk = 0; chunk < nch_run; ++chunk) {
+      const bool more = chunk + 1 < nch_run;
+      const bool a_next = more || has_next;  // activations to stage at the end of this chunk
+      static_for(std::make_integer_sequence<int, C::NG>{}, [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr bool last_g = (g == C::NG - 1);
+        {
+          // group R-1 steps ahead: inside this tile, else the matching group of the next tile (else a harmless re-read)
+          int gi = chunk * C::NG + g + (R - 1);
+          int co0 = cur.co0;
+          if (gi >= NGT) {
+            gi -= NGT;
+            if (gi >= NGT) gi %= NGT;
+            co0 = nxt.co0;
           }
+          issue_G(gseq++, gi, co0);
+        }
+        if (g == A_G && a_next) {
+          if (more) load_A(cur, chunk + 1);
+          else load_A(nxt, 0);
+        }
+        const float4* Bg = Bs + (step % R) * C::G_F4;
 #pragma unroll
-          for (int c = 0; c < NT; ++c) {
-            bh[c].f4 = Bc[seg * C::BN + b_base[c]];
-            bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
-          }
+        for (int u = 0; u < TPS; ++u) {
+          const int tap = g * TPS + u;
+          const int tapoff = (TAPS == 9) ? ((tap / 3) * C::WT + (tap % 3)) : 0;
+          const float4* Bc = Bg + u * C::B_F4;
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
+          for (int s = 0; s < 2; ++s) {
+            const int seg = s * 2 + h;
+            F4H8b ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              ah[i].f4 = As[seg * C::HP + a_base[i] + tapoff];
+              al[i].f4 = As[(4 + seg) * C::HP + a_base[i] + tapoff];
+            }
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
-              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
-              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+              bh[c].f4 = Bc[seg * C::BN + b_base[c]];
+              bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
             }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int c = 0; c < NT; ++c) {
+                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
+                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+              }
+          }
         }
-      }
-      if (last_g) {
-        if (more) {
-          __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
-          store_A();                     // (compiler-inserted wait covers the areg loads)
-          wait_vmcnt<BASE>();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ++step;
+        if (last_g) {
+          if (a_next) {
+            __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
+            store_A();                     // (compiler-inserted wait covers the areg loads)
+            wait_vmcnt<BASE>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          }
+        } else {
+          // the activation loads were issued right after the group of step (A_G)+R-1: they are younger than the next
+          // group while g - A_G <= R-2
+          constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
+          if (a_younger && a_next) wait_vmcnt<BASE + C::A_CNT>();
+          else wait_vmcnt<BASE>();
           __builtin_amdgcn_s_barrier();
         }
-      } else {
-        // the activation loads were issued right after group (A_G step)+R-1: they are younger than group G+1
-        // while g - A_G <= R-2
-        constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
-        if (a_younger && more) wait_vmcnt<BASE + C::A_CNT>();
-        else wait_vmcnt<BASE>();
-        __builtin_amdgcn_s_barrier();
+      });
+    }
+
+    // ---- epilogue of the current tile.  Rows of a 32x32 accumulator tile held by this lane: 8g + 4h + k (g, k = 0..3);
+    // the four k rows are four consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per
+    // (i, g).  Loads are issued unconditionally on clamped addresses (batched ahead of the math); stores are predicated
+    // and fire-and-forget: they drain while the next tile's main loop runs.
+    if (!(a.dbg & 32))  // experiment switch: skip the epilogue
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      size_t pixb[4];
+      int nimg[4];
+      bool okg[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = (wm * MT + i) * 32 + 8 * g + 4 * h;
+        const int img = row / PPI, py = (row / TW) % TH, px = row % TW;
+        const int n = cur.n0 + img;
+        okg[g] = n < a.N;
+        nimg[g] = okg[g] ? n : a.N - 1;
+        pixb[g] = ((size_t)nimg[g] * a.H + (cur.ty0 + py)) * a.W + (cur.tx0 + px);
       }
-    });
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const int col = (wn * NT + c) * 32 + r;
+        const int co = cur.co0 + col;
+        const float bias = a.bias ? a.bias[co] : 0.f;
+        float rv[16], ev[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ev[g] = a.emb ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
+        if (a.res) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rv[e] = a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+        }
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // rows 0-15 / 16-31 of this tile (two images when PPI == 16)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int g = e >> 2;
+          const float v = acc[i][c][e] * inv_scale + bias + ev[g] + rv[e];
+          acc[i][c][e] = 0.f;  // ready for the next tile
+          if (okg[g]) {
+            if (a.out_nchw) {
+              if (co < a.cout_valid) {
+                const size_t pix = pixb[g] + (e & 3);
+                const size_t hw = (size_t)a.H * a.W;
+                a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v;
+              }
+            } else {
+              a.out[(pixb[g] + (e & 3)) * a.Cout + co] = v;
+            }
+            if (e < 8) {
+              s0 += v;
+              q0 += v * v;
+            } else {
+              s1 += v;
+              q1 += v * v;
+            }
+          }
+        }
+        if (st) {
+          const int row0 = (wm * MT + i) * 32;
+          if (PPI >= 32) {
+            s0 += s1;
+            q0 += q1;
+          }
+          double* d = lst + ((size_t)(row0 / PPI) * C::BN + col) * 2;
+          atomicAdd(d, (double)s0);
+          atomicAdd(d + 1, (double)q0);
+          if (PPI < 32) {
+            double* d2 = lst + ((size_t)((row0 + 16) / PPI) * C::BN + col) * 2;
+            atomicAdd(d2, (double)s1);
+            atomicAdd(d2 + 1, (double)q1);
+          }
+        }
+      }
+    }
+    if (st) {
+      // fold of this tile's statistics: LDS -> one global fp64 atomic per (image, channel, moment); re-zero for the next tile
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) {
+        const int img = k / (C::BN * 2), rem = k % (C::BN * 2);
+        const int n = cur.n0 + img;
+        if (n < a.N) atomicAdd(reinterpret_cast<double*>(a.stat_out + (size_t)n * a.Cout + cur.co0) + rem, lst[k]);
+        lst[k] = 0.0;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!has_next) break;
+    k_tile += J;
+    cur = nxt;
   }
   wait_vmcnt<0>();  // drain the tail DMAs before the workgroup's LDS can be re-assigned
-
-  const float inv_scale = a.w_inv_scale ? *a.w_inv_scale : 1.0f;
-  // GroupNorm statistics of the output, fused into the epilogue: per (image in tile, column) sum / sum of squares are
-  // folded in LDS (fp32 partials per lane -> fp64 LDS atomics), then ONE global fp64 atomic per (image, channel, moment)
-  // per workgroup.  The activation tile in LDS is dead by now and is reused for the fold.
-  constexpr int PPI = TH * TW;  // GEMM rows per image inside the tile: 16 .. 256
-  const bool st = a.stat_out != nullptr;
-  double* lst = reinterpret_cast<double*>(lds);  // [TN][BN][2]
-  if (st) {
-    __builtin_amdgcn_s_barrier();  // every wave is done with the activation tile
-    for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) lst[k] = 0.0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  // Rows of a 32x32 accumulator tile held by this lane: 8g + 4h + k (g = 0..3, k = 0..3); the four k rows are four
-  // consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per (i, g).  All loads are issued
-  // unconditionally on clamped addresses (batched ahead of the math); only the stores are predicated.
-  if (!(a.dbg & 32))  // experiment switch: skip the epilogue
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    size_t pixb[4];
-    int nimg[4];
-    bool okg[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row = (wm * MT + i) * 32 + 8 * g + 4 * h;
-      const int img = row / PPI, py = (row / TW) % TH, px = row % TW;
-      const int n = n0 + img;
-      okg[g] = n < a.N;
-      nimg[g] = okg[g] ? n : a.N - 1;
-      pixb[g] = ((size_t)nimg[g] * a.H + (ty0 + py)) * a.W + (tx0 + px);
-    }
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      const int col = (wn * NT + c) * 32 + r;
-      const int co = co0 + col;
-      const float bias = a.bias ? a.bias[co] : 0.f;
-      float rv[16], ev[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) ev[g] = a.emb ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
-      if (a.res) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) rv[e] = a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) rv[e] = 0.f;
-      }
-      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // rows 0-15 / 16-31 of this tile (two images when PPI == 16)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int g = e >> 2;
-        const float v = acc[i][c][e] * inv_scale + bias + ev[g] + rv[e];
-        if (okg[g]) {
-          if (a.out_nchw) {
-            if (co < a.cout_valid) {
-              const size_t pix = pixb[g] + (e & 3);
-              const size_t hw = (size_t)a.H * a.W;
-              a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v;
-            }
-          } else {
-            a.out[(pixb[g] + (e & 3)) * a.Cout + co] = v;
-          }
-          if (e < 8) {
-            s0 += v;
-            q0 += v * v;
-          } else {
-            s1 += v;
-            q1 += v * v;
-          }
-        }
-      }
-      if (st) {
-        const int row0 = (wm * MT + i) * 32;
-        if (PPI >= 32) {
-          s0 += s1;
-          q0 += q1;
-        }
-        double* d = lst + ((size_t)(row0 / PPI) * C::BN + col) * 2;
-        atomicAdd(d, (double)s0);
-        atomicAdd(d + 1, (double)q0);
-        if (PPI < 32) {
-          double* d2 = lst + ((size_t)((row0 + 16) / PPI) * C::BN + col) * 2;
-          atomicAdd(d2, (double)s1);
-          atomicAdd(d2 + 1, (double)q1);
-        }
-      }
-    }
-  }
-  if (st) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) {
-      const int img = k / (C::BN * 2), rem = k % (C::BN * 2);
-      const int n = n0 + img;
-      if (n < a.N) atomicAdd(reinterpret_cast<double*>(a.stat_out + (size_t)n * a.Cout + co0) + rem, lst[k]);
-    }
-  }
 }
 
 template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS>
@@ -424,8 +481,14 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int groups = (a.N + C::TN - 1) / C::TN;
-  const long long blocks = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
-  DRM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid size");
+  const long long tiles = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
+  DRM_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv grid size");
+  // persistent grid: as many workgroups as stay resident (256 CUs x workgroups per CU by LDS), a multiple of 8 (XCDs)
+  static const int no_persist = getenv("DRM_S2_NOPERSIST") ? 1 : 0;
+  const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds_bytes), 8 / C::NW));
+  long long grid = 256ll * per_cu;
+  const int ngt = ((a.C0 + a.C1) / C::KC) * C::NG;  // weight groups per tile
+  if (no_persist || tiles < grid || ngt < R - 1) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
   {
     const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
     const double px = (double)a.N * a.H * a.W;
@@ -433,13 +496,13 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     prof_tag(a.N, a.H, a.W, a.C0 + a.C1, a.Cout);
     ProfScope ps(TAPS == 9 ? PROF_CONV3 : PROF_CONV1, 2.0 * px * TAPS * cin * cout,
                  4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NTHR), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHR), lds_bytes, s, a);
   }
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }
 
-// 256-pixel x {128, 64}-channel tiles on 8 waves (ring of 4), 128-pixel x 32-channel tiles on 4 waves
+// 256-pixel x {128, 64}-channel tiles on 8 waves, 128-pixel x {64, 32}-channel tiles on 4 waves
 template <int TAPS, int TH, int TW, int TH4, int TW4>
 static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   // Deep U-Net levels (4x8 .. 8x16 maps) have few GEMM rows: with 256x128 tiles they launch far fewer workgroups than
@@ -447,21 +510,18 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   const long long rows = (long long)a.N * a.H * a.W;
   auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
   // 3x3: one barrier per kernel ROW (3 taps, 48 KB of weights per step, double-buffered); 1x1: one tap per step, ring of 4.
-  // The 256-row tile on 4x4 maps keeps the one-tap ring (its 16-image halo tile leaves no room for 96 KB of weights).
+  // 256-row tiles on 4x8 / 4x4 maps keep the one-tap ring (their multi-image halo tiles leave no room for 96 KB of weights).
   constexpr int TPS = (TAPS == 9) ? 3 : 1;
   constexpr int RG = (TAPS == 9) ? 2 : 4;
-  constexpr bool big_ok = (TAPS == 1) || !(TH == 4 && TW == 4);
-  static const int small_tiles = getenv("DRM_S2_SMALL") ? atoi(getenv("DRM_S2_SMALL")) : 0;  // experiment switch
-  if (small_tiles && a.Cout % 128 == 0 && wgs(128, 128) >= 512) {
-    if (small_tiles == 1) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1>(a, s);  // 128x128 tiles, 4 waves, 2 WGs/CU
-    if (small_tiles == 3) return launch_s2<TAPS, TH, TW, 4, 1, 2, 2, 4, 1>(a, s);    // 256x64 tiles, 4 waves, 2 WGs/CU
-    return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 4, 1>(a, s);
-  }
+  constexpr bool big_ok = (TAPS == 1) || (TH >= 8);
   if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) {
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS>(a, s);
-    else return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4, 1>(a, s);
+    else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1>(a, s);
   }
-  if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS>(a, s);
+  if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) {
+    if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS>(a, s);
+    else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS>(a, s);
+  }
   if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS>(a, s);
   return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS>(a, s);
 }

@@ -251,6 +251,12 @@ class DRMNet(nn.Module):
     def p_sample(self, Lr_k, illnet_cond, refnet_cond, reversed_k, return_model_out=False):
         raise NotImplementedError("")  # the reference leaves this unimplemented too (drmnet.py:772-780)
 
+    def set_precision(self, precision: str) -> "DRMNet":
+        """Conv arithmetic of both networks: "fp32" (exact fp32 MFMA) or "f16x3" (split fp16, fp32-accurate, ~3x faster)."""
+        self.illnet_model.diffusion_model.set_precision(precision)
+        self.refnet_model.diffusion_model.set_precision(precision)
+        return self
+
     # ------------------------------------------------------------------ the device sampler
     def _engine(self):
         ill, ref = self.illnet_model.diffusion_model, self.refnet_model.diffusion_model
@@ -258,7 +264,7 @@ class DRMNet(nn.Module):
         zp = [p.detach() for p in self.illnet_model.z_emb_params()]
         for p in zp:
             _lib.require_gpu_tensor(p, "z_emb_layer parameter")
-        sig = (hi.value, hr.value, tuple((p.data_ptr(), p._version) for p in zp), float(self.gamma), float(self.epsilon), float(self.delta),
+        sig = (hi.value, hr.value, ill.precision, ref.precision, tuple((p.data_ptr(), p._version) for p in zp), float(self.gamma), float(self.epsilon), float(self.delta),
                int(self.max_timesteps), tuple(self._z0.tolist()))
         if self._sampler is not None and sig == self._sampler_sig:
             return self._sampler

@@ -37,10 +37,11 @@ def tiny_drmnet(g, dev):
     return m.to(dev)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("tag", ["a", "b"])
-def test_drmnet_p_sample_loop_vs_reference_trace(dev, tag):
+def test_drmnet_p_sample_loop_vs_reference_trace(dev, tag, precision):
     g = gold(f"drmnet_loop_{tag}")
-    m = tiny_drmnet(g, dev)
+    m = tiny_drmnet(g, dev).set_precision(precision)
     LrK = torch.from_numpy(g["LrK"]).to(dev)
     n0 = torch.from_numpy(g["noise0"]).to(dev)
     sn = torch.from_numpy(g["step_noise"]).to(dev)
@@ -85,12 +86,13 @@ def tiny_obsnet(dev):
     return m.to(dev)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("eta", [0, 1])
-def test_ddim_sample_vs_reference_trace(dev, eta):
+def test_ddim_sample_vs_reference_trace(dev, eta, precision):
     from drmnet_amd.ddim import DDIMSampler
 
     g = gold(f"ddim_trace_eta{eta}")
-    m = tiny_obsnet(dev)
+    m = tiny_obsnet(dev).set_precision(precision)
     cond, x_T, noise = (torch.from_numpy(g[k]).to(dev) for k in ("cond", "x_T", "noise"))
     s = DDIMSampler(m)
     x1, _ = s.sample(50, cond.shape[0], (3, 16, 16), cond, eta=float(eta), x_T=x_T, verbose=False, noise=noise, num_steps=1)
