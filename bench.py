@@ -238,10 +238,27 @@ def main():
             kname = ("conv_igemm_split_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp16 hi/lo x3 v_mfma_f32_32x32x16_f16, fp32 accumulate; "
                      "achieved counts ALGORITHMIC FLOPs, the matrix cores execute 3x that)") if split else \
                 "conv_igemm_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp32 v_mfma_f32_32x32x2_f32)"
+            kname = kname.replace("conv_igemm_split_kernel", "conv_split2_kernel")
             roofline = {"bound": "mfma", "kernel": kname,
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": None, "launches": int(n[0]), "avg_launch_ms": round(ms[0] / n[0], 4),
-                        "flops_per_launch": round(fl[0] / n[0], 1), "share_of_step_time": round(ms[0] * 1e-3 / dt, 3)}
+                        "flops_per_launch": round(fl[0] / n[0], 1), "algorithmic_bytes_per_launch": round(by[0] / n[0], 1),
+                        "share_of_step_time": round(ms[0] * 1e-3 / dt, 3)}
+            if split:  # the matrix cores execute three f16 MFMAs per algorithmic product
+                roofline["executed_mfma_tflops"] = round(3 * ach, 2)
+                roofline["executed_frac_of_f16_peak"] = round(3 * ach / peak, 4)
+                roofline["fp32_mfma_peak_for_reference"] = FP32_MFMA_PEAK_TFLOPS
+            # HBM traffic is a PMC quantity: it cannot be read from inside this process, so it is taken from the committed
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/), dominant variant, per launch
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                    pmc = json.load(f)["kernels"]
+                key = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3>"
+                if split and key in pmc and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256):
+                    roofline["traffic"] = pmc[key]["hbm_bytes_per_launch_corrected"]
+                    roofline["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch of " + key + ")"
+            except (OSError, KeyError, ValueError):
+                pass
 
     if rank == 0:
         total_steps = args.batch * world * args.steps
