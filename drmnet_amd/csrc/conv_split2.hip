@@ -38,12 +38,21 @@ struct S2Cfg {
   static constexpr int TN = BM / (TH * TW);
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
   static constexpr int HT = TH + 2 * HALO, WT = TW + 2 * HALO;
-  static constexpr int HPI = HT * WT;
-  static constexpr int HP = TN * HPI;
+  static constexpr int HPI = HT * WT;  // halo pixels per image that are loaded
+  // LDS image of the halo tile.  With 16-pixel-wide tiles the 32 rows of an MFMA tile are a 4 x 8 pixel patch and the
+  // halo rows are stored 24 pixels apart: the four 16-lane groups of a ds_read_b128 then hit 64 distinct banks for every
+  // tap offset (stride = 8 mod 16 pixels; the natural 18-pixel stride with 2 x 16 patches measured 35 % conflict cycles).
+  static constexpr bool SUB48 = (TW % 8 == 0) && (TH % 4 == 0);
+  static constexpr int WTP_TRY = (TAPS == 9 && TW == 16) ? 24 : WT;
+  static constexpr bool PAD_FITS = ((TAPS == 1 ? 2 : 1) * 8 * TN * HT * WTP_TRY + R * TPS * 8 * (WN * NT * 32) + TN * (WN * NT * 32)) * 16 <= 160 * 1024;
+  static constexpr int WTP = PAD_FITS ? WTP_TRY : WT;  // stored row stride (pixels)
+  static constexpr int HPIP = HT * WTP;                // stored pixels per image
+  static constexpr int HP = TN * HPIP;
   static constexpr int TPI = NTHR / TN;  // loader threads per image
   static constexpr int OCT = 4;
   static constexpr int A_SLOTS = (HPI * OCT + TPI - 1) / TPI;
-  static constexpr int A_F4 = 8 * HP;
+  static constexpr int A1_F4 = 8 * HP;                       // one activation tile image
+  static constexpr int A_F4 = (TAPS == 1 ? 2 : 1) * A1_F4;  // 1x1: double-buffered (a new tile every step)
   static constexpr int B_F4 = 8 * BN;
   static constexpr int B_PER = B_F4 / NTHR;  // LDS-DMA instructions per wave per weight tile
   static constexpr int NG = TAPS / TPS;      // pipeline steps ("groups" of TPS taps) per 32-channel chunk
@@ -52,6 +61,21 @@ struct S2Cfg {
   static constexpr int ST_F4 = TN * BN;      // statistics fold area: [TN][BN] x (sum, sumsq) doubles == one float4 each
   static constexpr int LDS_F4 = A_F4 + R * G_F4 + ST_F4;
   static constexpr int A_CNT = 2 * A_SLOTS + 4;  // ordinary VGPR loads per thread per chunk (activations + GroupNorm scale/shift)
+  // GEMM row of the tile (0 .. BM-1) -> (image in tile, pixel row, pixel column)
+  static __device__ __forceinline__ void rowmap(int row, int& img, int& py, int& px) {
+    if constexpr (SUB48) {
+      constexpr int SPI = (TH / 4) * (TW / 8);  // 32-row patches per image
+      const int q = row >> 5, rr = row & 31;
+      img = q / SPI;
+      const int qq = q % SPI;
+      py = (qq / (TW / 8)) * 4 + (rr >> 3);
+      px = (qq % (TW / 8)) * 8 + (rr & 7);
+    } else {
+      img = row / (TH * TW);
+      py = (row / TW) % TH;
+      px = row % TW;
+    }
+  }
   static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
   static_assert(B_F4 % NTHR == 0 && B_PER >= 1, "every wave issues the same number of LDS-DMA loads per tile");
   static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       sc[0] = ps[0]; sc[1] = ps[1]; sh[0] = pb[0]; sh[1] = pb[1];
     }
   };
-  auto store_A = [&]() {
+  auto store_A = [&](float4* Ad) {
 #pragma unroll
     for (int j = 0; j < C::A_SLOTS; ++j) {
       const int lidx = l_tid + C::TPI * j;
@@ -212,9 +236,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           hi.h8[k] = hh;
           lo.h8[k] = ll;
         }
-        const int pixel = l_img * C::HPI + lidx / C::OCT;
-        As[l_o * C::HP + pixel] = hi.f4;
-        As[(4 + l_o) * C::HP + pixel] = lo.f4;
+        const int hpl = lidx / C::OCT;
+        const int pixel = l_img * C::HPIP + (hpl / C::WT) * C::WTP + (hpl % C::WT);
+        Ad[l_o * C::HP + pixel] = hi.f4;
+        Ad[(4 + l_o) * C::HP + pixel] = lo.f4;
       }
     }
   };
@@ -243,8 +268,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int row = (wm * MT + i) * 32 + r;
-    const int img = row / (TH * TW), py = (row / TW) % TH, px = row % TW;
-    a_base[i] = img * C::HPI + py * C::WT + px;
+    int img, py, px;
+    C::rowmap(row, img, py, px);
+    a_base[i] = img * C::HPIP + py * C::WTP + px;
   }
 #pragma unroll
   for (int c = 0; c < NT; ++c) b_base[c] = (wn * NT + c) * 32 + r;
@@ -284,8 +310,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     }
   }
   load_A(cur, 0);
-  store_A();  // the compiler's own wait for the areg loads also retires the (older) DMA groups
-  wait_vmcnt<0>();
+  store_A(As);  // the compiler's own wait for the areg loads also retires the (older) DMA groups
+  if (TAPS == 1) {  // 1x1: the activations of step 1 are requested a full step ahead
+    if (nchunks > 1) load_A(cur, 1);
+    else if (k_tile + J < x_count) load_A(decode(x_start + k_tile + J), 0);
+  } else {
+    wait_vmcnt<0>();
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -301,6 +332,61 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   while (true) {
     const bool has_next = k_tile + J < x_count;
     const TilePos nxt = has_next ? decode(x_start + k_tile + J) : cur;
+    if constexpr (TAPS == 1) {
+      // 1x1 pipeline: one 32-channel chunk per step, activation tiles double-buffered in LDS.  areg always holds the
+      // NEXT step's activations (requested one step ago); after the MFMAs they are staged into the other LDS buffer and
+      // the loads of the step after next are issued, so every load has a whole step of MFMAs to land.
+      for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool n1 = (chunk + 1 < nchunks) || has_next;                      // a next step exists
+        const bool n2 = (chunk + 2 < nchunks) || (has_next && nchunks >= 2);    // ... and one after it (persistent mode needs nchunks >= 2)
+        {
+          int gi = chunk + (R - 1);
+          int co0 = cur.co0;
+          if (gi >= NGT) {
+            gi -= NGT;
+            if (gi >= NGT) gi %= NGT;
+            co0 = nxt.co0;
+          }
+          issue_G(gseq++, gi, co0);
+        }
+        const float4* Ab = As + (step & 1) * C::A1_F4;
+        const float4* Bc = Bs + (step % R) * C::G_F4;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int seg = s2 * 2 + h;
+          F4H8b ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            ah[i].f4 = Ab[seg * C::HP + a_base[i]];
+            al[i].f4 = Ab[(4 + seg) * C::HP + a_base[i]];
+          }
+#pragma unroll
+          for (int c = 0; c < NT; ++c) {
+            bh[c].f4 = Bc[seg * C::BN + b_base[c]];
+            bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+            }
+        }
+        ++step;
+        if (n1) store_A(As + (step & 1) * C::A1_F4);  // the buffer read one step ago: every wave passed that step's barrier
+        if (n2) {
+          if (chunk + 2 < nchunks) load_A(cur, chunk + 2);
+          else load_A(nxt, chunk + 2 - nchunks);
+          wait_vmcnt<BASE + C::A_CNT>();
+        } else {
+          wait_vmcnt<BASE>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
     const int nch_run = (a.dbg & 64) ? 1 : nchunks;  // experiment switch: run a single K chunk
     for (int chunk = 0; chunk < nch_run; ++chunk) {
       const bool more = chunk + 1 < nch_run;
@@ -327,7 +413,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
         for (int u = 0; u < TPS; ++u) {
           const int tap = g * TPS + u;
-          const int tapoff = (TAPS == 9) ? ((tap / 3) * C::WT + (tap % 3)) : 0;
+          const int tapoff = (TAPS == 9) ? ((tap / 3) * C::WTP + (tap % 3)) : 0;
           const float4* Bc = Bg + u * C::B_F4;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
@@ -357,7 +443,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         if (last_g) {
           if (a_next) {
             __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
-            store_A();                     // (compiler-inserted wait covers the areg loads)
+            store_A(As);                   // (compiler-inserted wait covers the areg loads)
             wait_vmcnt<BASE>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -373,6 +459,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       });
     }
 
+    }
+
     // ---- epilogue of the current tile.  Rows of a 32x32 accumulator tile held by this lane: 8g + 4h + k (g, k = 0..3);
     // the four k rows are four consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per
     // (i, g).  Loads are issued unconditionally on clamped addresses (batched ahead of the math); stores are predicated
@@ -386,7 +474,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row = (wm * MT + i) * 32 + 8 * g + 4 * h;
-        const int img = row / PPI, py = (row / TW) % TH, px = row % TW;
+        int img, py, px;
+        C::rowmap(row, img, py, px);
         const int n = cur.n0 + img;
         okg[g] = n < a.N;
         nimg[g] = okg[g] ? n : a.N - 1;
@@ -488,7 +577,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
   const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds_bytes), 8 / C::NW));
   long long grid = 256ll * per_cu;
   const int ngt = ((a.C0 + a.C1) / C::KC) * C::NG;  // weight groups per tile
-  if (no_persist || tiles < grid || ngt < R - 1) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
+  if (no_persist || tiles < grid || ngt < R - 1 || (TAPS == 1 && ngt < 2)) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
   {
     const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
     const double px = (double)a.N * a.H * a.W;
