@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdrmnet_hip.so")
+# DRM_LIB=exp selects the experiment build of tools/build_exp.sh (kernel-internals timing switches; never the default)
+LIB_PATH = os.path.join(_HERE, "csrc", "libdrmnet_hip_exp.so" if os.environ.get("DRM_LIB") == "exp" else "libdrmnet_hip.so")
 MAX_LEVELS = 8
 
 # every symbol include/drmnet_hip.h declares (tests check the .so exports all of them)

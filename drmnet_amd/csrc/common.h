@@ -65,6 +65,7 @@ struct ConvArgs {
   float* out = nullptr;             // NHWC [N,H,W,Cout], or NCHW [N,cout_valid,H,W] if out_nchw
   int out_nchw = 0, cout_valid = 0;
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
+  unsigned long long* trace = nullptr;  // experiment build only: per-wave phase cycle counters
   int dbg = 0;                         // experiment switches (DRM_DBG env): 1 skip B reloads, 2 skip A reloads, 4 skip MFMA, 8 skip barriers
   double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)
   const float* w_inv_scale = nullptr;  // split-precision path: device scalar 2^-k undoing the weight pre-scaling

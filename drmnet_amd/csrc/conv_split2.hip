@@ -19,9 +19,28 @@
 // All vector-memory operations a wave issues are unconditional (clamped addresses, zero-filled afterwards) so the
 // vmcnt bookkeeping below is exact and identical for every wave.
 #include <utility>
+#include <vector>
+#include <cstdio>
 
 #include "common.h"
 #include "profiler.h"
+
+// Experiment build (-DDRM_S2_EXP, tools/build_exp.sh): DRM_DBG bits switch parts of the 3x3 main loop off so their
+// cost can be read off a timing difference.  1 no weight DMA, 2 no activation staging, 4 no LDS reads + MFMAs,
+// 8 MFMAs from stale registers (no LDS fragment reads), 16 no barriers.  The product build has none of these branches.
+#ifdef DRM_S2_EXP
+#define S2X(bit) (a.dbg & (bit))
+#else
+#define S2X(bit) 0
+#endif
+// Phase timers of the experiment build: s_memtime deltas accumulated per wave (0 weight DMA issue, 1 activation load issue,
+// 2 LDS fragment reads + MFMA issue, 3 counted vmcnt wait, 4 barrier, 5 activation staging, 6 epilogue, 7 statistics fold).
+#ifdef DRM_S2_EXP
+#define TSTAMP(k) do { const unsigned long long t_now_ = clock64(); tacc[k] += t_now_ - t_prev; t_prev = t_now_; } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+#define S2_BARRIER() do { if (!S2X(16)) __builtin_amdgcn_s_barrier(); } while (0)
 
 namespace drm {
 
@@ -44,7 +63,12 @@ struct S2Cfg {
   // tap offset (stride = 8 mod 16 pixels; the natural 18-pixel stride with 2 x 16 patches measured 35 % conflict cycles).
   static constexpr bool SUB48 = (TW % 8 == 0) && (TH % 4 == 0);
   static constexpr int WTP_TRY = (TAPS == 9 && TW == 16) ? 24 : WT;
-  static constexpr bool PAD_FITS = ((TAPS == 1 ? 2 : 1) * 8 * TN * HT * WTP_TRY + R * TPS * 8 * (WN * NT * 32) + TN * (WN * NT * 32)) * 16 <= 160 * 1024;
+  static constexpr int RING_ST_F4 = R * TPS * 8 * (WN * NT * 32) + TN * (WN * NT * 32);
+  // 3x3 with one tap per step and a >= 4-slot ring: the halo tile is double-buffered when two copies fit, so the
+  // GroupNorm/SiLU/split staging of the next chunk runs under the MFMAs of this one instead of between two barriers.
+  static constexpr bool DB = (TAPS == 9) && (TPS == 1) && (R >= 4) && (2 * 8 * TN * HT * WT + RING_ST_F4) * 16 <= 160 * 1024;
+  static constexpr int A_COPIES = (TAPS == 1 || DB) ? 2 : 1;
+  static constexpr bool PAD_FITS = (A_COPIES * 8 * TN * HT * WTP_TRY + RING_ST_F4) * 16 <= 160 * 1024;
   static constexpr int WTP = PAD_FITS ? WTP_TRY : WT;  // stored row stride (pixels)
   static constexpr int HPIP = HT * WTP;                // stored pixels per image
   static constexpr int HP = TN * HPIP;
@@ -52,7 +76,7 @@ struct S2Cfg {
   static constexpr int OCT = 4;
   static constexpr int A_SLOTS = (HPI * OCT + TPI - 1) / TPI;
   static constexpr int A1_F4 = 8 * HP;                       // one activation tile image
-  static constexpr int A_F4 = (TAPS == 1 ? 2 : 1) * A1_F4;  // 1x1: double-buffered (a new tile every step)
+  static constexpr int A_F4 = A_COPIES * A1_F4;  // 1x1: double-buffered (a new tile every step)
   static constexpr int B_F4 = 8 * BN;
   static constexpr int B_PER = B_F4 / NTHR;  // LDS-DMA instructions per wave per weight tile
   static constexpr int NG = TAPS / TPS;      // pipeline steps ("groups" of TPS taps) per 32-channel chunk
@@ -82,7 +106,9 @@ struct S2Cfg {
   static_assert(R >= 2, "ring needs >= 2 slots");
 };
 
-__device__ __forceinline__ float silu2(float v) { return v / (1.0f + __expf(-v)); }
+// v * sigmoid(v) with v_rcp_f32 (1 ulp) in place of the IEEE division sequence (11 VALU instructions per value inside the
+// activation staging, which runs on the same SIMDs as the MFMAs); the hi/lo fp16 split that follows keeps 22 bits anyway.
+__device__ __forceinline__ float silu2(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
   const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
   hi = (_Float16)c;
@@ -160,6 +186,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   };
   int k_tile = jx;  // index inside this XCD's range
   if (k_tile >= x_count) return;
+#ifdef DRM_S2_EXP
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = clock64();
+  unsigned long long t_prev = t_begin;
+#endif
   TilePos cur = decode(x_start + k_tile);
 
   const int Ctot = a.C0 + a.C1;
@@ -326,9 +357,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   //   (3) MFMAs of the TPS taps of the group,
   //   (4) counted wait: everything up to the next group landed; allowed in flight = the R-2 younger groups
   //       (+ the activation loads while they are younger than the next group), then ONE barrier per TPS taps.
-  constexpr int A_G = (C::NG >= 3) ? C::NG - 2 : 0;
+  //   Double-buffered 3x3 (C::DB): the request goes out at group 2, is complete (in-order retirement) by the end of group
+  //   2+R-1, and is staged into the OTHER tile buffer at the start of group 2+R; no extra barrier.
+  constexpr int A_G = C::DB ? 2 : ((C::NG >= 3) ? C::NG - 2 : 0);
+  constexpr int STORE_G = A_G + R;
+  static_assert(!C::DB || STORE_G + 1 <= C::NG - 1, "double-buffered staging must fit inside the chunk");
   constexpr int BASE = C::G_PER * (R - 2);
   int step = 0;  // steps executed so far (== gseq - (R-1))
+  int abuf = 0;  // activation tile buffer being read (double-buffered 3x3)
+#ifdef DRM_S2_EXP
+  F4H8b ah[MT], al[MT], bh[NT], bl[NT];  // bit 8: MFMAs run on whatever these hold
+  for (int i = 0; i < MT; ++i) ah[i].f4 = al[i].f4 = As[tid];
+  for (int c = 0; c < NT; ++c) bh[c].f4 = bl[c].f4 = As[tid + 64];
+#endif
   while (true) {
     const bool has_next = k_tile + J < x_count;
     const TilePos nxt = has_next ? decode(x_start + k_tile + J) : cur;
@@ -394,6 +435,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       static_for(std::make_integer_sequence<int, C::NG>{}, [&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr bool last_g = (g == C::NG - 1);
+        if constexpr (C::DB) {
+          // before this step's DMA goes out: the compiler's own wait for the staged registers also drains DMA
+          // The two waves of a SIMD (w and w+4) stage in different steps: one converts while the other runs MFMAs.
+          if constexpr (g == STORE_G) {
+            if (wave < C::NW / 2 && a_next && !S2X(2)) store_A(As + (abuf ^ 1) * C::A1_F4);
+          }
+          if constexpr (g == STORE_G + 1) {
+            if (wave >= C::NW / 2 && a_next && !S2X(2)) store_A(As + (abuf ^ 1) * C::A1_F4);
+          }
+          TSTAMP(5);
+        }
         {
           // group R-1 steps ahead: inside this tile, else the matching group of the next tile (else a harmless re-read)
           int gi = chunk * C::NG + g + (R - 1);
@@ -403,13 +455,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             if (gi >= NGT) gi %= NGT;
             co0 = nxt.co0;
           }
-          issue_G(gseq++, gi, co0);
+          if (!S2X(1)) issue_G(gseq, gi, co0);
+          ++gseq;
         }
-        if (g == A_G && a_next) {
+        TSTAMP(0);
+        if (g == A_G && a_next && !S2X(2)) {
           if (more) load_A(cur, chunk + 1);
           else load_A(nxt, 0);
         }
+        TSTAMP(1);
         const float4* Bg = Bs + (step % R) * C::G_F4;
+        const float4* Ac = As + (C::DB ? abuf * C::A1_F4 : 0);
+        if (!S2X(4))
 #pragma unroll
         for (int u = 0; u < TPS; ++u) {
           const int tap = g * TPS + u;
@@ -418,16 +475,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const int seg = s * 2 + h;
+#ifndef DRM_S2_EXP
             F4H8b ah[MT], al[MT], bh[NT], bl[NT];
+#endif
+            if (!S2X(8)) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-              ah[i].f4 = As[seg * C::HP + a_base[i] + tapoff];
-              al[i].f4 = As[(4 + seg) * C::HP + a_base[i] + tapoff];
-            }
+              for (int i = 0; i < MT; ++i) {
+                ah[i].f4 = Ac[seg * C::HP + a_base[i] + tapoff];
+                al[i].f4 = Ac[(4 + seg) * C::HP + a_base[i] + tapoff];
+              }
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-              bh[c].f4 = Bc[seg * C::BN + b_base[c]];
-              bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
+              for (int c = 0; c < NT; ++c) {
+                bh[c].f4 = Bc[seg * C::BN + b_base[c]];
+                bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
+              }
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -440,13 +501,27 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           }
         }
         ++step;
-        if (last_g) {
-          if (a_next) {
-            __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
+        TSTAMP(2);
+        if constexpr (C::DB) {
+          constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
+          if (a_younger && a_next) wait_vmcnt<BASE + C::A_CNT>();
+          else wait_vmcnt<BASE>();
+          if (last_g) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staged tile is visible to every wave
+          TSTAMP(3);
+          S2_BARRIER();
+          TSTAMP(4);
+          if (last_g && a_next) abuf ^= 1;
+        } else if (last_g) {
+          if (a_next && !S2X(2)) {
+            S2_BARRIER();  // every wave finished reading the old activation tile
+            TSTAMP(4);
             store_A(As);                   // (compiler-inserted wait covers the areg loads)
+            TSTAMP(5);
             wait_vmcnt<BASE>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            TSTAMP(3);
+            S2_BARRIER();
+            TSTAMP(4);
           }
         } else {
           // the activation loads were issued right after the group of step (A_G)+R-1: they are younger than the next
@@ -454,7 +529,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
           if (a_younger && a_next) wait_vmcnt<BASE + C::A_CNT>();
           else wait_vmcnt<BASE>();
-          __builtin_amdgcn_s_barrier();
+          TSTAMP(3);
+          S2_BARRIER();
+          TSTAMP(4);
         }
       });
     }
@@ -538,6 +615,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         }
       }
     }
+    TSTAMP(6);
     if (st) {
       // fold of this tile's statistics: LDS -> one global fp64 atomic per (image, channel, moment); re-zero for the next tile
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -551,10 +629,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    TSTAMP(7);
     if (!has_next) break;
     k_tile += J;
     cur = nxt;
   }
+#ifdef DRM_S2_EXP
+  if (a.trace && lane == 0) {
+    unsigned long long* tr = a.trace + ((size_t)blockIdx.x * C::NW + wave) * 10;
+    for (int k = 0; k < 8; ++k) tr[k] = tacc[k];
+    tr[8] = clock64() - t_begin;
+    tr[9] = 1;
+  }
+#endif
   wait_vmcnt<0>();  // drain the tail DMAs before the workgroup's LDS can be re-assigned
 }
 
@@ -585,7 +672,40 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     prof_tag(a.N, a.H, a.W, a.C0 + a.C1, a.Cout);
     ProfScope ps(TAPS == 9 ? PROF_CONV3 : PROF_CONV1, 2.0 * px * TAPS * cin * cout,
                  4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
+#ifdef DRM_S2_EXP
+    static unsigned long long* trace_buf = nullptr;
+    static const int want_trace = getenv("DRM_S2_TRACE") ? 1 : 0;
+    ConvArgs at = a;
+    const size_t trace_n = (size_t)grid * C::NW * 10;
+    if (want_trace && TAPS == 9) {
+      if (!trace_buf) DRM_HIP_CHECK(hipMalloc(&trace_buf, (size_t)1 << 26));
+      DRM_HIP_CHECK(hipMemsetAsync(trace_buf, 0, trace_n * 8, s));
+      at.trace = trace_buf;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHR), lds_bytes, s, at);
+    if (at.trace) {
+      std::vector<unsigned long long> h(trace_n);
+      DRM_HIP_CHECK(hipStreamSynchronize(s));
+      DRM_HIP_CHECK(hipMemcpy(h.data(), trace_buf, trace_n * 8, hipMemcpyDeviceToHost));
+      double acc[9] = {0}, lo[2][9] = {{0}};
+      size_t nw = 0, nlo[2] = {0, 0};
+      for (size_t w = 0; w < (size_t)grid * C::NW; ++w) {
+        if (!h[w * 10 + 9]) continue;
+        ++nw;
+        const int half = (int)(w % C::NW) >= C::NW / 2;
+        ++nlo[half];
+        for (int k = 0; k < 9; ++k) { acc[k] += (double)h[w * 10 + k]; lo[half][k] += (double)h[w * 10 + k]; }
+      }
+      fprintf(stderr, "s2 trace <%d,%d,%d,%d,%d,%d,%d,R%d,TPS%d> C%d->%d %dx%d grid %lld: mean cycles/wave total %.0f | dma %.0f loadA %.0f mfma %.0f vmwait %.0f barrier %.0f stage %.0f epi %.0f fold %.0f\n",
+              TAPS, TH, TW, WM, WN, MT, NT, R, TPS, a.C0 + a.C1, a.Cout, a.H, a.W, grid, acc[8] / nw, acc[0] / nw, acc[1] / nw, acc[2] / nw,
+              acc[3] / nw, acc[4] / nw, acc[5] / nw, acc[6] / nw, acc[7] / nw);
+      for (int hf = 0; hf < 2; ++hf)
+        fprintf(stderr, "   waves %s: mfma %.0f vmwait %.0f barrier %.0f stage %.0f epi %.0f\n", hf ? "4-7" : "0-3", lo[hf][2] / nlo[hf], lo[hf][3] / nlo[hf],
+                lo[hf][4] / nlo[hf], lo[hf][5] / nlo[hf], lo[hf][6] / nlo[hf]);
+    }
+#else
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHR), lds_bytes, s, a);
+#endif
   }
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
@@ -603,11 +723,22 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   constexpr int TPS = (TAPS == 9) ? 3 : 1;
   constexpr int RG = (TAPS == 9) ? 2 : 4;
   constexpr bool big_ok = (TAPS == 1) || (TH >= 8);
+  static const int no_db = getenv("DRM_S2_DB") ? 0 : 1;  // A/B switch: DRM_S2_DB=1 selects the double-buffered halo tile variants
   if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) {
+    if constexpr (TAPS == 9 && big_ok) {
+      if constexpr (S2Cfg<TAPS, TH, TW, 4, 2, 2, 2, 4, 1>::DB) {
+        if (!no_db) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4, 1>(a, s);
+      }
+    }
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1>(a, s);
   }
   if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) {
+    if constexpr (TAPS == 9 && big_ok) {
+      if constexpr (S2Cfg<TAPS, TH, TW, 4, 2, 2, 1, 4, 1>::DB) {
+        if (!no_db) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, 4, 1>(a, s);
+      }
+    }
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS>(a, s);
   }

@@ -1,0 +1,118 @@
+// Sustained-MFMA microbenchmark for gfx950: registers only, no memory traffic.  Prints the achieved TFLOP/s of
+// v_mfma_f32_32x32x16_f16 and v_mfma_f32_32x32x2_f32 at 1 / 2 waves per SIMD so the conv kernels can be priced against what
+// the chip sustains under its power limit rather than the data-sheet clock.
+//   hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o gpurun_out/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int ACCS>
+__global__ __launch_bounds__(512) void k_f16(float* out, int iters, float seed) {
+  f32x16 acc[ACCS];
+  for (int i = 0; i < ACCS; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  f16x8 a, b;
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (_Float16)(seed + threadIdx.x * 1e-3f);
+    b[e] = (_Float16)(seed * 0.5f + e);
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < ACCS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < ACCS; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int ACCS>
+__global__ __launch_bounds__(512) void k_f32(float* out, int iters, float seed) {
+  f32x16 acc[ACCS];
+  for (int i = 0; i < ACCS; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float a = seed + threadIdx.x * 1e-3f, b = seed * 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < ACCS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < ACCS; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Dependency-distance variants of the split-precision inner product: 4 accumulators x 3 MFMAs each, issue order pinned.
+// DIST = 1: AAA BBB CCC DDD, 2: ABABAB CDCDCD (what hipcc emits for conv_split2), 4: ABCD ABCD ABCD.
+template <int DIST>
+__global__ __launch_bounds__(512) void k_dep(float* out, int iters, float seed) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  f16x8 a[3], b[3];
+  for (int k = 0; k < 3; ++k)
+    for (int e = 0; e < 8; ++e) {
+      a[k][e] = (_Float16)(seed + threadIdx.x * 1e-3f + k);
+      b[k][e] = (_Float16)(seed * 0.5f + e - k);
+    }
+#define MF(i, k) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k], b[k], acc[i], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+  for (int it = 0; it < iters; ++it) {
+    if (DIST == 1) {
+      MF(0, 0); MF(0, 1); MF(0, 2); MF(1, 0); MF(1, 1); MF(1, 2); MF(2, 0); MF(2, 1); MF(2, 2); MF(3, 0); MF(3, 1); MF(3, 2);
+    } else if (DIST == 2) {
+      MF(0, 0); MF(1, 0); MF(0, 1); MF(1, 1); MF(0, 2); MF(1, 2); MF(2, 0); MF(3, 0); MF(2, 1); MF(3, 1); MF(2, 2); MF(3, 2);
+    } else {
+      MF(0, 0); MF(1, 0); MF(2, 0); MF(3, 0); MF(0, 1); MF(1, 1); MF(2, 1); MF(3, 1); MF(0, 2); MF(1, 2); MF(2, 2); MF(3, 2);
+    }
+  }
+#undef MF
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <typename K>
+static void run(const char* name, K kern, int threads, int blocks, int iters, double flop_per_mfma, int accs, float* out, double secs) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, iters / 10, 1.0f);
+  hipDeviceSynchronize();
+  // repeat launches for `secs` seconds so the power controller reaches steady state; report the last launch
+  double tf = 0, total_ms = 0;
+  while (total_ms < secs * 1e3) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    total_ms += ms;
+    const double waves = (double)blocks * threads / 64;
+    tf = waves * iters * accs * flop_per_mfma / (ms * 1e-3) / 1e12;
+  }
+  printf("%-28s blocks=%d threads=%d  last launch: %.1f TFLOP/s\n", name, blocks, threads, tf);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const double secs = argc > 1 ? atof(argv[1]) : 3.0;
+  float* out;
+  hipMalloc(&out, 4096 * 512 * 4);
+  const double F16 = 2.0 * 32 * 32 * 16, F32 = 2.0 * 32 * 32 * 2;
+  run("f16 32x32x16, 1 wave/SIMD", k_f16<4>, 256, 256, 200000, F16, 4, out, secs);
+  run("f16 32x32x16, 2 waves/SIMD", k_f16<4>, 512, 256, 100000, F16, 4, out, secs);
+  run("f16 dep distance 1, 1 w/SIMD", k_dep<1>, 256, 256, 60000, F16, 12, out, secs);
+  run("f16 dep distance 1, 2 w/SIMD", k_dep<1>, 512, 256, 30000, F16, 12, out, secs);
+  run("f16 dep distance 2, 1 w/SIMD", k_dep<2>, 256, 256, 60000, F16, 12, out, secs);
+  run("f16 dep distance 2, 2 w/SIMD", k_dep<2>, 512, 256, 30000, F16, 12, out, secs);
+  run("f16 dep distance 4, 1 w/SIMD", k_dep<4>, 256, 256, 60000, F16, 12, out, secs);
+  run("f16 dep distance 4, 2 w/SIMD", k_dep<4>, 512, 256, 30000, F16, 12, out, secs);
+  run("f32 32x32x2, 1 wave/SIMD", k_f32<4>, 256, 256, 100000, F32, 4, out, secs);
+  run("f32 32x32x2, 2 waves/SIMD", k_f32<4>, 512, 256, 50000, F32, 4, out, secs);
+  return 0;
+}
