@@ -138,6 +138,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "memory");
 }
 
+// Activation loads are issued from inline asm as well: a compiler-visible load makes hipcc put s_waitcnt vmcnt(0) in front
+// of its first use, which also drains every LDS-DMA weight group in flight (measured: ~1.2 us stall per 32-channel chunk).
+// The destinations are tied to the counted wait that precedes their first use (tie_regs) -- cdna_hip_programming.md 5.7.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload16x2(f32x4& d0, f32x4& d1, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(d0), "=&v"(d1) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void tie_regs(f32x4& x0, f32x4& x1) { asm volatile("" : "+v"(x0), "+v"(x1)::"memory"); }
+
 template <int... I, typename F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -202,11 +211,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   const int l_img = tid / C::TPI;
   const int l_tid = tid % C::TPI;
   const int l_o = tid % C::OCT;
-  float4 areg[C::A_SLOTS][2];
-  float4 sc[2], sh[2];
+  f32x4 areg[C::A_SLOTS][2];
+  f32x4 sc[2], sh[2];
   unsigned avalid = 0;
 
-  auto load_A = [&](const TilePos& tp, int chunk) {
+  auto load_A_piece = [&](const TilePos& tp, int chunk, int piece) {
     const int c = chunk * C::KC;
     const float* src;
     int Cs, coff, up;
@@ -218,9 +227,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     const int Hs = up ? (a.H >> 1) : a.H, Ws = up ? (a.W >> 1) : a.W;
     const int l_n = tp.n0 + l_img;
     const int l_nc = l_n < a.N ? l_n : a.N - 1;
-    avalid = 0;
+    if (piece == 0) avalid = 0;
 #pragma unroll
     for (int j = 0; j < C::A_SLOTS; ++j) {
+      if (j != piece) continue;
       const int lidx = l_tid + C::TPI * j;
       const int hpl = lidx / C::OCT;
       const int hy = hpl / C::WT, hx = hpl % C::WT;
@@ -229,22 +239,29 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
       const int ys = up ? (yc >> 1) : yc, xs = up ? (xc >> 1) : xc;
       const size_t pix = ((size_t)l_nc * Hs + ys) * Ws + xs;
-      const float4* p = reinterpret_cast<const float4*>(src + pix * Cs + coff + 8 * l_o);
-      areg[j][0] = p[0];
-      areg[j][1] = p[1];
+      gload16x2(areg[j][0], areg[j][1], src + pix * Cs + coff + 8 * l_o);
       if (ok) avalid |= 1u << j;
     }
-    {  // always 4 loads (a harmless re-read of the input when there is no GroupNorm) so every chunk issues A_CNT loads
+    if (piece == C::A_SLOTS) {  // always 4 loads (a harmless re-read of the input when there is no GroupNorm) so every chunk issues A_CNT loads
       const float* gs = has_gn ? a.gn_scale + (size_t)l_nc * Ctot + c + 8 * l_o : a.src0;
       const float* gb = has_gn ? a.gn_shift + (size_t)l_nc * Ctot + c + 8 * l_o : a.src0;
-      const float4* ps = reinterpret_cast<const float4*>(gs);
-      const float4* pb = reinterpret_cast<const float4*>(gb);
-      sc[0] = ps[0]; sc[1] = ps[1]; sh[0] = pb[0]; sh[1] = pb[1];
+      gload16x2(sc[0], sc[1], gs);
+      gload16x2(sh[0], sh[1], gb);
     }
   };
-  auto store_A = [&](float4* Ad) {
+  auto load_A = [&](const TilePos& tp, int chunk) {
 #pragma unroll
-    for (int j = 0; j < C::A_SLOTS; ++j) {
+    for (int p = 0; p <= C::A_SLOTS; ++p) load_A_piece(tp, chunk, p);
+  };
+  // the loads of load_A have landed (a counted wait came first): make every later use of their registers depend on this point
+  auto tie_A = [&]() {
+#pragma unroll
+    for (int j = 0; j < C::A_SLOTS; ++j) tie_regs(areg[j][0], areg[j][1]);
+    tie_regs(sc[0], sc[1]);
+    tie_regs(sh[0], sh[1]);
+  };
+  auto store_A_slot = [&](float4* Ad, int j) {
+    {
       const int lidx = l_tid + C::TPI * j;
       if (lidx < C::HPI * C::OCT) {
         F4H8b hi, lo;
@@ -274,10 +291,27 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       }
     }
   };
+  auto store_A = [&](float4* Ad) {
+    tie_A();
+#pragma unroll
+    for (int j = 0; j < C::A_SLOTS; ++j) store_A_slot(Ad, j);
+  };
   // ---- weight groups: LDS-DMA, G_PER x 1 KiB per wave per group; LDS image == packed global layout.
   //      `gseq` counts groups since kernel start (ring slot = gseq % R); (g_in_tile, co0) say which weights.
   const unsigned lds_bs = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Bs));  // LDS byte offset of the ring
+  // k-th LDS-DMA instruction (0 .. G_PER-1) of a group
+  auto issue_G1 = [&](int gseq, int g_in_tile, int co0, int k) {
+    const int slot = gseq % R;
+    const int chunk = g_in_tile / C::NG, g = g_in_tile - chunk * C::NG;
+    const int u = k / C::B_PER, j = k % C::B_PER;
+    const int tap = g * TPS + u;
+    const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nchunks + chunk) * 8) * a.Cout + co0;
+    const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
+    const int idx = base + lane;
+    const int seg = idx / C::BN, co = idx % C::BN;
+    glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
+  };
   auto issue_G = [&](int gseq, int g_in_tile, int co0) {
     const int slot = gseq % R;
     const int chunk = g_in_tile / C::NG, g = g_in_tile - chunk * C::NG;
@@ -341,12 +375,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     }
   }
   load_A(cur, 0);
-  store_A(As);  // the compiler's own wait for the areg loads also retires the (older) DMA groups
+  wait_vmcnt<0>();
+  store_A(As);
   if (TAPS == 1) {  // 1x1: the activations of step 1 are requested a full step ahead
     if (nchunks > 1) load_A(cur, 1);
     else if (k_tile + J < x_count) load_A(decode(x_start + k_tile + J), 0);
-  } else {
-    wait_vmcnt<0>();
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -361,7 +394,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   //   2+R-1, and is staged into the OTHER tile buffer at the start of group 2+R; no extra barrier.
   constexpr int A_G = C::DB ? 2 : ((C::NG >= 3) ? C::NG - 2 : 0);
   constexpr int STORE_G = A_G + R;
-  static_assert(!C::DB || STORE_G + 1 <= C::NG - 1, "double-buffered staging must fit inside the chunk");
+  constexpr int STORE_STEPS = C::DB ? C::NG - STORE_G : 1;  // staging slots are dealt to the last steps of the chunk
+  static_assert(!C::DB || STORE_STEPS >= 1, "double-buffered staging must fit inside the chunk");
+  // The two waves that share a SIMD (w and w + NW/2 of an 8-wave workgroup) run the two halves of every step in opposite
+  // order: one issues DMA / loads / staging VALU work while the other owns the MFMA pipe, then they swap.  Measured with
+  // the phase timers of the experiment build: with every wave doing the same phase at the same time the MFMA pipe sat
+  // idle 55 % of the main loop (17 % in DMA issue alone: the CU's texture-address path serialises the 1-KiB DMAs).
+  const bool y_first = (C::NW == 8) && (wave >= C::NW / 2) && !(a.dbg & 128);
   constexpr int BASE = C::G_PER * (R - 2);
   int step = 0;  // steps executed so far (== gseq - (R-1))
   int abuf = 0;  // activation tile buffer being read (double-buffered 3x3)
@@ -373,57 +412,82 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   while (true) {
     const bool has_next = k_tile + J < x_count;
     const TilePos nxt = has_next ? decode(x_start + k_tile + J) : cur;
-    if constexpr (TAPS == 1) {
-      // 1x1 pipeline: one 32-channel chunk per step, activation tiles double-buffered in LDS.  areg always holds the
-      // NEXT step's activations (requested one step ago); after the MFMAs they are staged into the other LDS buffer and
-      // the loads of the step after next are issued, so every load has a whole step of MFMAs to land.
-      for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool n1 = (chunk + 1 < nchunks) || has_next;                      // a next step exists
-        const bool n2 = (chunk + 2 < nchunks) || (has_next && nchunks >= 2);    // ... and one after it (persistent mode needs nchunks >= 2)
-        {
-          int gi = chunk + (R - 1);
-          int co0 = cur.co0;
-          if (gi >= NGT) {
-            gi -= NGT;
-            if (gi >= NGT) gi %= NGT;
-            co0 = nxt.co0;
-          }
-          issue_G(gseq++, gi, co0);
-        }
-        const float4* Ab = As + (step & 1) * C::A1_F4;
-        const float4* Bc = Bs + (step % R) * C::G_F4;
+    // One tap (or 32-channel slab pair) of MFMAs: LDS fragment reads + 3 MFMAs per 32x32x16 product
+    auto mma_tap = [&](const float4* Ab, const float4* Bc, int tapoff, auto&& hook) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int seg = s2 * 2 + h;
-          F4H8b ah[MT], al[MT], bh[NT], bl[NT];
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int seg = s2 * 2 + h;
+#ifndef DRM_S2_EXP
+        F4H8b ah[MT], al[MT], bh[NT], bl[NT];
+#endif
+        if (!S2X(8)) {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            ah[i].f4 = Ab[seg * C::HP + a_base[i]];
-            al[i].f4 = Ab[(4 + seg) * C::HP + a_base[i]];
+            ah[i].f4 = Ab[seg * C::HP + a_base[i] + tapoff];
+            al[i].f4 = Ab[(4 + seg) * C::HP + a_base[i] + tapoff];
           }
 #pragma unroll
           for (int c = 0; c < NT; ++c) {
             bh[c].f4 = Bc[seg * C::BN + b_base[c]];
             bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
           }
+        }
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
-              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+          for (int c = 0; c < NT; ++c) {
+            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+            if (i == 0 && c == 0) {
+              // memory-side instructions of this step go out here, a few at a time, behind MFMAs that keep the pipe busy
+              // while the (blocking) vector-memory issue waits for the CU's address path
+              __builtin_amdgcn_sched_barrier(0);
+              hook(s2);
+              __builtin_amdgcn_sched_barrier(0);
             }
-        }
+          }
+      }
+    };
+    // group R-1 steps ahead of tile-local group index gi0: inside this tile, else the matching group of the next tile
+    // (else a harmless re-read)
+    auto issue_ahead = [&](int gi0) {
+      int gi = gi0 + (R - 1);
+      int co0 = cur.co0;
+      if (gi >= NGT) {
+        gi -= NGT;
+        if (gi >= NGT) gi %= NGT;
+        co0 = nxt.co0;
+      }
+      if (!S2X(1)) issue_G(gseq, gi, co0);
+      ++gseq;
+    };
+    if constexpr (TAPS == 1) {
+      // 1x1 pipeline: one 32-channel chunk per step, activation tiles double-buffered in LDS.  areg always holds the
+      // NEXT step's activations (requested one step ago).  "Side work" of a step = stage them into the other LDS buffer,
+      // request the step after next, issue the weight DMA R-1 steps ahead; the activation request goes out BEFORE the
+      // DMA so that waiting for it (in-order retirement) never waits for a younger weight group.
+      for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool n1 = (chunk + 1 < nchunks) || has_next;                      // a next step exists
+        const bool n2 = (chunk + 2 < nchunks) || (has_next && nchunks >= 2);    // ... and one after it (persistent mode needs nchunks >= 2)
+        auto side = [&]() {
+          if (n1) {
+            if (step == 0) wait_vmcnt<0>();       // first step: the request is the youngest operation
+            else wait_vmcnt<C::G_PER>();          // younger: the weight group issued right after it
+            store_A(As + ((step + 1) & 1) * C::A1_F4);  // the buffer read one step ago: every wave passed that barrier
+          }
+          if (n2) {
+            if (chunk + 2 < nchunks) load_A(cur, chunk + 2);
+            else load_A(nxt, chunk + 2 - nchunks);
+          }
+          issue_ahead(chunk);
+        };
+        if (!y_first) side();
+        mma_tap(As + (step & 1) * C::A1_F4, Bs + (step % R) * C::G_F4, 0, [](int) {});
+        if (y_first) side();
         ++step;
-        if (n1) store_A(As + (step & 1) * C::A1_F4);  // the buffer read one step ago: every wave passed that step's barrier
-        if (n2) {
-          if (chunk + 2 < nchunks) load_A(cur, chunk + 2);
-          else load_A(nxt, chunk + 2 - nchunks);
-          wait_vmcnt<BASE + C::A_CNT>();
-        } else {
-          wait_vmcnt<BASE>();
-        }
+        if (n2) wait_vmcnt<BASE + C::A_CNT>();
+        else wait_vmcnt<BASE>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
@@ -435,78 +499,69 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       static_for(std::make_integer_sequence<int, C::NG>{}, [&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr bool last_g = (g == C::NG - 1);
-        if constexpr (C::DB) {
-          // before this step's DMA goes out: the compiler's own wait for the staged registers also drains DMA
-          // The two waves of a SIMD (w and w+4) stage in different steps: one converts while the other runs MFMAs.
-          if constexpr (g == STORE_G) {
-            if (wave < C::NW / 2 && a_next && !S2X(2)) store_A(As + (abuf ^ 1) * C::A1_F4);
-          }
-          if constexpr (g == STORE_G + 1) {
-            if (wave >= C::NW / 2 && a_next && !S2X(2)) store_A(As + (abuf ^ 1) * C::A1_F4);
-          }
-          TSTAMP(5);
-        }
-        {
-          // group R-1 steps ahead: inside this tile, else the matching group of the next tile (else a harmless re-read)
-          int gi = chunk * C::NG + g + (R - 1);
-          int co0 = cur.co0;
-          if (gi >= NGT) {
-            gi -= NGT;
-            if (gi >= NGT) gi %= NGT;
-            co0 = nxt.co0;
-          }
-          if (!S2X(1)) issue_G(gseq, gi, co0);
-          ++gseq;
-        }
-        TSTAMP(0);
-        if (g == A_G && a_next && !S2X(2)) {
-          if (more) load_A(cur, chunk + 1);
-          else load_A(nxt, 0);
-        }
-        TSTAMP(1);
-        const float4* Bg = Bs + (step % R) * C::G_F4;
-        const float4* Ac = As + (C::DB ? abuf * C::A1_F4 : 0);
-        if (!S2X(4))
+        // side work of the step: staging slots of the double-buffered tile, weight DMA R-1 steps ahead, activation request
+        auto side = [&]() {
+          if constexpr (C::DB && g >= STORE_G) {
+            if (a_next && !S2X(2)) {
+              if (g == STORE_G) tie_A();  // complete since the counted wait that ended step STORE_G-1
 #pragma unroll
-        for (int u = 0; u < TPS; ++u) {
-          const int tap = g * TPS + u;
-          const int tapoff = (TAPS == 9) ? ((tap / 3) * C::WTP + (tap % 3)) : 0;
-          const float4* Bc = Bg + u * C::B_F4;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int seg = s * 2 + h;
-#ifndef DRM_S2_EXP
-            F4H8b ah[MT], al[MT], bh[NT], bl[NT];
-#endif
-            if (!S2X(8)) {
-#pragma unroll
-              for (int i = 0; i < MT; ++i) {
-                ah[i].f4 = Ac[seg * C::HP + a_base[i] + tapoff];
-                al[i].f4 = Ac[(4 + seg) * C::HP + a_base[i] + tapoff];
-              }
-#pragma unroll
-              for (int c = 0; c < NT; ++c) {
-                bh[c].f4 = Bc[seg * C::BN + b_base[c]];
-                bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
-              }
+              for (int j = 0; j < C::A_SLOTS; ++j)
+                if (STORE_G + (j % STORE_STEPS) == g) store_A_slot(As + (abuf ^ 1) * C::A1_F4, j);
             }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int c = 0; c < NT; ++c) {
-                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
-                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-              }
           }
+        };
+        // group R-1 steps ahead: inside this tile, else the matching group of the next tile (else a harmless re-read)
+        int d_gi = chunk * C::NG + g + (R - 1);
+        int d_co0 = cur.co0;
+        if (d_gi >= NGT) {
+          d_gi -= NGT;
+          if (d_gi >= NGT) d_gi %= NGT;
+          d_co0 = nxt.co0;
         }
-        ++step;
+        const int d_seq = gseq++;
+        const bool a_req = (g == A_G) && a_next && !S2X(2);
+        // Hook points of a step: 2 per tap (one per 16-channel slab).  The DMA instructions go to the first hook points,
+        // the activation request (in pieces) to the later ones, so the request stays younger than the whole group.
+        constexpr int HPN = 2 * TPS;
+        constexpr int DMA_HP = (HPN >= 4) ? HPN / 2 : HPN;  // hook points that carry DMA
+        constexpr int A_HP0 = (HPN >= 4) ? HPN / 2 : HPN - 1;  // first hook point of the activation request
+        constexpr int A_PIECES = C::A_SLOTS + 1;
+        auto compute = [&]() {
+          const float4* Bg = Bs + (step % R) * C::G_F4;
+          const float4* Ac = As + (C::DB ? abuf * C::A1_F4 : 0);
+          if (!S2X(4))
+#pragma unroll
+          for (int u = 0; u < TPS; ++u) {
+            const int tap = g * TPS + u;
+            mma_tap(Ac, Bg + u * C::B_F4, (tap / 3) * C::WTP + (tap % 3), [&](int s2) {
+              const int hp = u * 2 + s2;
+              if (hp < DMA_HP && !S2X(1)) {
+#pragma unroll
+                for (int k = hp * C::G_PER / DMA_HP; k < (hp + 1) * C::G_PER / DMA_HP; ++k) issue_G1(d_seq, d_gi, d_co0, k);
+              }
+              if (hp >= A_HP0 && a_req) {
+                const int q = hp - A_HP0, nq = HPN - A_HP0;
+#pragma unroll
+                for (int pc = q * A_PIECES / nq; pc < (q + 1) * A_PIECES / nq; ++pc) {
+                  if (more) load_A_piece(cur, chunk + 1, pc);
+                  else load_A_piece(nxt, 0, pc);
+                }
+              }
+            });
+          }
+        };
+        if (!y_first) side();
+        TSTAMP(0);
+        compute();
         TSTAMP(2);
+        if (y_first) side();
+        TSTAMP(0);
+        ++step;
+        constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
         if constexpr (C::DB) {
-          constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
           if (a_younger && a_next) wait_vmcnt<BASE + C::A_CNT>();
           else wait_vmcnt<BASE>();
-          if (last_g) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staged tile is visible to every wave
+          if (g >= STORE_G) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staged slots visible before the tile is read
           TSTAMP(3);
           S2_BARRIER();
           TSTAMP(4);
@@ -515,18 +570,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           if (a_next && !S2X(2)) {
             S2_BARRIER();  // every wave finished reading the old activation tile
             TSTAMP(4);
-            store_A(As);                   // (compiler-inserted wait covers the areg loads)
+            wait_vmcnt<C::G_PER * (C::NG - 1 - A_G)>();  // the request of group A_G; younger: the weight groups issued after it
+            store_A(As);
             TSTAMP(5);
             wait_vmcnt<BASE>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             TSTAMP(3);
             S2_BARRIER();
             TSTAMP(4);
+          } else {
+            wait_vmcnt<BASE>();
+            S2_BARRIER();
           }
         } else {
           // the activation loads were issued right after the group of step (A_G)+R-1: they are younger than the next
           // group while g - A_G <= R-2
-          constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
           if (a_younger && a_next) wait_vmcnt<BASE + C::A_CNT>();
           else wait_vmcnt<BASE>();
           TSTAMP(3);
