@@ -20,6 +20,7 @@
 namespace drm {
 
 int launch_conv_split2(const ConvArgs& a, hipStream_t s);
+int launch_conv_split3(const ConvArgs& a, hipStream_t s, bool& handled);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -358,7 +359,15 @@ int launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
   DRM_REQUIRE(a.Cout % 32 == 0 && Ctot % 32 == 0 && a.C0 % 32 == 0, "split conv needs channels % 32 == 0");
   DRM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "conv shape");
   DRM_REQUIRE(!a.up0 || (a.H % 2 == 0 && a.W % 2 == 0), "upsampled source needs even output size");
-  if (!split_v1()) return launch_conv_split2(a, s);  // LDS-DMA weight ring, 256-pixel tiles (conv_split2.hip)
+  if (!split_v1()) {
+    static const int use_s3 = getenv("DRM_S3") ? atoi(getenv("DRM_S3")) : 0;
+    if (use_s3 && a.taps == 9) {  // producer / consumer waves (conv_split3.hip) for the 3x3 layers that fill the chip
+      bool handled = false;
+      const int rc = launch_conv_split3(a, s, handled);
+      if (handled) return rc;
+    }
+    return launch_conv_split2(a, s);  // LDS-DMA weight ring, 256-pixel tiles (conv_split2.hip)
+  }
   if (a.taps == 9) return dispatch_split_tile<9>(a, s);
   return dispatch_split_tile<1>(a, s);
 }
