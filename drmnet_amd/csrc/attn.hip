@@ -114,6 +114,99 @@ __global__ __launch_bounds__(256) void bgemm64_kernel(const float* __restrict__ 
   }
 }
 
+// Split-precision form of the same batched GEMM (see conv_split.hip): both operands are split into fp16 hi + lo while
+// they are staged, each 32x32x16 product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation
+// (~2^-22 relative per product).  A is multiplied by a_scale (a power of two) before the split -- softmax probabilities
+// would otherwise sit in fp16's subnormal range -- and alpha carries the inverse.  Needs K % 32 == 0.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+union AF4H8 {
+  float4 f4;
+  f16x8 h8;
+};
+__device__ __forceinline__ void split8(const float (&v)[8], float scale, float4& hi, float4& lo) {
+  AF4H8 h, l;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float c = __builtin_amdgcn_fmed3f(v[k] * scale, -65504.0f, 65504.0f);
+    const _Float16 hh = (_Float16)c;
+    h.h8[k] = hh;
+    l.h8[k] = (_Float16)(c - (float)hh);
+  }
+  hi = h.f4;
+  lo = l.f4;
+}
+
+template <bool BT>
+__global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm, int M,
+                                                       int Ncols, int K, int lda, int ldb, int ldc, long long sA, long long sB, long long sC,
+                                                       float alpha, float a_scale) {
+  __shared__ float4 As[2 * 4 * 64];  // [hl][octet of the 32-wide K chunk][row]
+  __shared__ float4 Bs[2 * 4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  A += (size_t)blockIdx.z * sA;
+  B += (size_t)blockIdx.z * sB;
+  Cm += (size_t)blockIdx.z * sC;
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    {  // A: one (row, octet) per thread, 32 contiguous bytes
+      const int row = tid >> 2, oct = tid & 3;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (m0 + row < M) {
+        const float4* p = reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k0 + 8 * oct);
+        const float4 x = p[0], y = p[1];
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+      }
+      split8(v, a_scale, As[oct * 64 + row], As[(4 + oct) * 64 + row]);
+    }
+    if (BT) {
+      const int col = tid >> 2, oct = tid & 3;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (n0 + col < Ncols) {
+        const float4* p = reinterpret_cast<const float4*>(B + (size_t)(n0 + col) * ldb + k0 + 8 * oct);
+        const float4 x = p[0], y = p[1];
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+      }
+      split8(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+    } else {
+      const int oct = tid >> 6, col = tid & 63;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (n0 + col < Ncols) {
+        const float* p = B + (size_t)(k0 + 8 * oct) * ldb + n0 + col;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(size_t)j * ldb];
+      }
+      split8(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int oct = 2 * s2 + h;
+      AF4H8 ah, al, bh, bl;
+      ah.f4 = As[oct * 64 + wm * 32 + r];
+      al.f4 = As[(4 + oct) * 64 + wm * 32 + r];
+      bh.f4 = Bs[oct * 64 + wn * 32 + r];
+      bl.f4 = Bs[(4 + oct) * 64 + wn * 32 + r];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h8, bh.h8, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bl.h8, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bh.h8, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn * 32 + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (row < M && col < Ncols) Cm[(size_t)row * ldc + col] = alpha * acc[e];
+  }
+}
+
 // in-place softmax over the last axis; one wave per row
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, long long rows, int T) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -136,20 +229,29 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
   for (int i = lane; i < T; i += 64) p[i] *= inv;
 }
 
-int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s) {
+int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, bool split) {
   DRM_REQUIRE(C % 4 == 0 && T > 0 && N > 0, "attention shape");
   const float alpha = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, applied once to the dot product
   const int tb = (T + 63) / 64;
   prof_tag(N, T, 1, C, C);
   ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C + 4.0 * T * T), s);
-  hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
-                     (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha);
+  split = split && (C % 32 == 0) && (T % 32 == 0);
+  if (split)
+    hipLaunchKernelGGL(bgemm64s_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
+                       (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha, 1.0f);
+  else
+    hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
+                       (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha);
   DRM_HIP_CHECK(hipGetLastError());
   const long long rows = (long long)N * T;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, scores, rows, T);
   DRM_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(bgemm64_kernel<false>, dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
-                     (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f);
+  if (split)  // probabilities are scaled by 2^12 before the fp16 split (largest 4096, smallest normal 2^-26)
+    hipLaunchKernelGGL(bgemm64s_kernel<false>, dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
+                       (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
+  else
+    hipLaunchKernelGGL(bgemm64_kernel<false>, dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
+                       (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }

@@ -92,7 +92,7 @@ int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* 
                        const float* beta, int N, float* scale, float* shift, hipStream_t s);
 
 // attention (attn.hip): qkv [N][T][3C] -> out [N][T][C]; scores workspace [N][T][T]
-int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s);
+int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, bool split = false);
 
 // misc kernels (misc.hip)
 int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s);

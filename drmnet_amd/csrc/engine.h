@@ -1,7 +1,9 @@
 // Network engine: block topology, parameter table, packed-weight storage and the forward schedule of
 // kernel launches for the reference U-Net family (ldm/modules/diffusionmodules/openaimodel.py).
 #pragma once
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/drmnet_hip.h"
@@ -32,6 +34,26 @@ struct Arena {
   }
   size_t mark() const { return off; }
   void release(size_t m) { off = m; }
+  // GroupNorm statistics pool of one forward pass: the [N][C] (sum, sumsq) tables of all activations, carved from one
+  // region that is zeroed by a single memset at the start of the pass (they are accumulated into by conv epilogues).
+  char* st_base = nullptr;
+  size_t st_cap = 0, st_off = 0;
+  bool st_active = false;  // dry mode: count the pool; real mode: st_base is valid and zeroed
+  void* alloc_stats(size_t bytes, bool* zeroed) {
+    if (!st_active) {
+      *zeroed = false;
+      return alloc_bytes(bytes);
+    }
+    const size_t a = (st_off + 255) & ~size_t(255);
+    st_off = a + bytes;
+    *zeroed = true;
+    if (dry) return nullptr;
+    if (st_off > st_cap) {
+      failed = true;
+      return nullptr;
+    }
+    return st_base + a;
+  }
 };
 
 struct Act {  // NHWC activation (+ cached per-channel moments for GroupNorm)
@@ -41,6 +63,7 @@ struct Act {  // NHWC activation (+ cached per-channel moments for GroupNorm)
   double2* mom = nullptr;   // [N][C] (mean, mean of squares)
   bool mom_valid = false;
   bool mom_sums = false;    // table holds raw sums over the stored pixels (fused conv-epilogue statistics) instead of means
+  bool mom_zeroed = false;  // table comes from the pass's pre-zeroed statistics pool
 };
 
 enum ParamKind { PK_COPY, PK_CONV };
@@ -79,6 +102,7 @@ class UNet {
   std::vector<std::vector<Layer>> input_blocks, output_blocks;  // input_blocks[0] is the stem (empty list)
   std::vector<Layer> middle;
   int final_ch = 0, emb_dim = 0, emb_total = 0, in_cp = 0, out_cp = 0;
+  size_t stem_s = 0;
   // packed-buffer offsets
   size_t te0_w = 0, te0_b = 0, te2_w = 0, te2_b = 0, stem_w = 0, stem_b = 0, embcat_w = 0, embcat_b = 0, on_w = 0, on_b = 0, oc_w = 0, oc_b = 0, oc_s = 0, scratch_off = 0;
   size_t wbuf_floats = 0;
@@ -89,6 +113,7 @@ class UNet {
 
   int build(const drm_unet_desc& d);
   int load(const float* const* ptrs, int count, hipStream_t s);
+  std::map<std::tuple<int, int, int>, size_t> stats_pool_cache;  // (N, H, W) -> bytes of the statistics pool
   int forward(const float* x, int Cx, const float* cond, int Cc, const int32_t* rows, const float* t_emb, const int64_t* t, const float* tf,
               float* out, int N, int H, int W, Arena& ar, hipStream_t s);
   ~UNet();

@@ -103,7 +103,7 @@ int UNet::build(const drm_unet_desc& d) {
   const int mc = d.model_channels;
   emb_dim = 4 * mc;
   DRM_REQUIRE(emb_dim <= 512, "time_embed_dim (4*model_channels) must be <= 512");
-  in_cp = round_up(d.in_channels, 8);
+  in_cp = round_up(d.in_channels, 32);  // one 32-channel K chunk: the stem runs on the same kernels as every other conv
   out_cp = 32;
   auto has_attn = [&](int ds) {
     for (int i = 0; i < d.n_attn; ++i)
@@ -115,7 +115,7 @@ int UNet::build(const drm_unet_desc& d) {
   te0_b = add_copy("time_embed.0.bias", {emb_dim});
   te2_w = add_copy("time_embed.2.weight", {emb_dim, emb_dim});
   te2_b = add_copy("time_embed.2.bias", {emb_dim});
-  stem_w = add_conv("input_blocks.0.0.weight", mc, d.in_channels, 3, mc, in_cp);
+  stem_w = add_conv("input_blocks.0.0.weight", mc, d.in_channels, 3, mc, in_cp, false, &stem_s);
   stem_b = add_copy("input_blocks.0.0.bias", {mc});
   input_blocks.emplace_back();
 
@@ -225,7 +225,7 @@ Act new_act(Ctx& c, int C, int H, int W) {
   Act a;
   a.C = C; a.H = H; a.W = W;
   a.p = c.ar->alloc<float>((size_t)c.N * H * W * C);
-  a.mom = c.ar->alloc<double2>((size_t)c.N * C);
+  a.mom = reinterpret_cast<double2*>(c.ar->alloc_stats((size_t)c.N * C * sizeof(double2), &a.mom_zeroed));
   return a;
 }
 
@@ -245,7 +245,7 @@ int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_
   if (c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0) {
     a.w_inv_scale = Wb + scale_off + 1;
     if (stats_for && !a.out_nchw && conv_split_fuses_stats()) {
-      DRM_HIP_CHECK(hipMemsetAsync(stats_for->mom, 0, (size_t)c.N * stats_for->C * sizeof(double2), c.s));
+      if (!stats_for->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(stats_for->mom, 0, (size_t)c.N * stats_for->C * sizeof(double2), c.s));
       a.stat_out = stats_for->mom;
       stats_for->mom_valid = true;
       stats_for->mom_sums = true;
@@ -325,7 +325,7 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
     a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
     a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.taps = 1; a.Cout = 3 * C; a.out = qkv;
     DRM_TRY(run_conv(c, a, Wb, l.qkv_s));
-    DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s));
+    DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split()));
     ConvArgs p;
     p.src0 = att; p.C0 = C; p.N = c.N; p.H = H; p.W = W;
     p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.taps = 1; p.Cout = C; p.res = x.p; p.out = out.p;
@@ -355,6 +355,31 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   const float* Wb = wbuf;
   const int mc = desc.model_channels;
 
+  // statistics pool: sized by a dry pass (cached per shape), zeroed once
+  ar.st_active = true;
+  ar.st_off = 0;
+  if (!ar.dry) {
+    const auto key = std::make_tuple(N, H, W);
+    auto it = stats_pool_cache.find(key);
+    if (it == stats_pool_cache.end()) {
+      Arena probe;
+      probe.dry = true;
+      DRM_TRY(forward(nullptr, Cx, nullptr, Cc, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, probe, s));
+      it = stats_pool_cache.emplace(key, probe.st_off).first;
+    }
+    ar.st_cap = it->second;
+    ar.st_base = reinterpret_cast<char*>(ar.alloc_bytes(ar.st_cap));
+    if (ar.st_base) DRM_HIP_CHECK(hipMemsetAsync(ar.st_base, 0, ar.st_cap, s));
+  }
+  struct PoolScope {  // the pool belongs to this pass only
+    Arena& a;
+    ~PoolScope() {
+      if (a.dry) a.peak += (a.st_off + 255) & ~size_t(255);
+      a.st_active = false;
+      a.st_base = nullptr;
+    }
+  } pool_scope{ar};
+
   Act xin = new_act(c, in_cp, H, W);
   float* temb = c.ar->alloc<float>((size_t)N * mc);
   float* e1 = c.ar->alloc<float>((size_t)N * emb_dim);
@@ -383,7 +408,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
     ConvArgs a;
     a.src0 = xin.p; a.C0 = in_cp; a.N = N; a.H = H; a.W = W;
     a.w = Wb + stem_w; a.bias = Wb + stem_b; a.taps = 9; a.Cout = mc; a.out = h->p; a.cin_real = desc.in_channels;
-    DRM_TRY(launch_conv(a, s));
+    DRM_TRY(run_conv(c, a, Wb, stem_s, h));
   }
   hs.push_back(h);
 

@@ -12,24 +12,33 @@ __device__ __forceinline__ float silu_m(float v) { return v / (1.0f + __expf(-v)
 // idx (optional) gathers rows: out row j reads sample idx[j] (DRMNet active-set compaction,
 // models/drmnet.py:810-813).
 // ---------------------------------------------------------------------------------------------
+// One thread per (pixel, 4-channel quad): the NHWC writes are fully coalesced 16-byte stores; only the first
+// (Cx + Cc + 3) / 4 quads read anything.
 __global__ void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ cond, const int* __restrict__ idx,
-                                  float* __restrict__ out, int N, int HW, int Cx, int Cc, int CP) {
+                                  float4* __restrict__ out, int N, int HW, int Cx, int Cc, int Q) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)N * HW) return;
-  const int n = (int)(i / HW), p = (int)(i % HW);
-  const int src = idx ? idx[n] : n;
-  float* o = out + i * CP;
-  for (int c = 0; c < CP; ++c) {
-    float v = 0.f;
-    if (c < Cx) v = x[((size_t)src * Cx + c) * HW + p];
-    else if (c < Cx + Cc) v = cond[((size_t)src * Cc + (c - Cx)) * HW + p];
-    o[c] = v;
+  if (i >= (long long)N * HW * Q) return;
+  const int q = (int)(i % Q);
+  const long long pix = i / Q;
+  const int n = (int)(pix / HW), p = (int)(pix % HW);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (4 * q < Cx + Cc) {
+    const int src = idx ? idx[n] : n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = 4 * q + k;
+      if (c < Cx) v[k] = x[((size_t)src * Cx + c) * HW + p];
+      else if (c < Cx + Cc) v[k] = cond[((size_t)src * Cc + (c - Cx)) * HW + p];
+    }
   }
+  out[i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s) {
-  const long long total = (long long)N * H * W;
-  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cond, idx, out, N, H * W, Cx, Cc, CP);
+  DRM_REQUIRE(CP % 4 == 0, "packed input channels must be a multiple of 4");
+  const long long total = (long long)N * H * W * (CP / 4);
+  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cond, idx, reinterpret_cast<float4*>(out), N,
+                     H * W, Cx, Cc, CP / 4);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }
@@ -102,7 +111,57 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ i
   }
 }
 
+// Matrix-core form for in_features % 16 == 0: out[n][o] = act_out(bias[o] + sum_i act_in(in[n][i]) * w[o][i]) as a
+// 32 (batch rows) x 32 (output features) x I GEMM per wave on v_mfma_f32_32x32x2_f32 (exact fp32 products).  Every lane
+// reads 8 consecutive floats of "its" input row and weight row per 16-wide K step; MFMA j of the step pairs the j-th of
+// them from the two half-waves, a permutation of k that both operands share.  Weights are read once per 32 batch rows.
+typedef float f32x16m __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ out, int N, int I, int O, int silu_in, int silu_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int o0 = (blockIdx.x * 4 + wave) * 32, n0 = blockIdx.y * 32;
+  if (o0 >= O) return;
+  const int n = min(n0 + r, N - 1), o = min(o0 + r, O - 1);
+  const float4* pi = reinterpret_cast<const float4*>(in + (size_t)n * I + 8 * h);
+  const float4* pw = reinterpret_cast<const float4*>(w + (size_t)o * I + 8 * h);
+  f32x16m acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll 4
+  for (int kb = 0; kb < I / 16; ++kb) {
+    const float4 a0 = pi[4 * kb], a1 = pi[4 * kb + 1];
+    const float4 w0 = pw[4 * kb], w1 = pw[4 * kb + 1];
+    float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    if (silu_in) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = silu_m(av[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wv[j], acc, 0, 0, 0);
+  }
+  const int oc = o0 + r;
+  if (oc < O) {
+    const float bias = b ? b[oc] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < N) {
+        float v = acc[e] + bias;
+        if (silu_out) v = silu_m(v);
+        out[(size_t)row * O + oc] = v;
+      }
+    }
+  }
+}
+
 int launch_linear(const float* in, const float* w, const float* b, float* out, int N, int I, int O, int silu_in, int silu_out, hipStream_t s) {
+  if (I % 16 == 0 && I >= 16) {
+    hipLaunchKernelGGL(linear_mfma_kernel, dim3((O + 127) / 128, (N + 31) / 32), dim3(256), 0, s, in, w, b, out, N, I, O, silu_in, silu_out);
+    DRM_HIP_CHECK(hipGetLastError());
+    return DRM_OK;
+  }
   DRM_REQUIRE(I > 0 && I <= 512, "linear: in_features must be <= 512");
   hipLaunchKernelGGL(linear_kernel, dim3((O + 3) / 4), dim3(256), 0, s, in, w, b, out, N, I, O, silu_in, silu_out);
   DRM_HIP_CHECK(hipGetLastError());

@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 kernel stats of a short bench run; prints the top kernels (name, calls, total ms, avg us)
+cd /tmp && export TMPDIR=/tmp
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_top
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_top -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_top.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import sqlite3, glob
+db = sorted(glob.glob('gpurun_out/prof_top/**/*_results.db', recursive=True))[-1]
+con = sqlite3.connect(db)
+rows = con.execute("select name, total_calls, total_duration, average from top_kernels order by total_duration desc limit 32").fetchall()
+for n, c, t, a in rows:
+    print(f"{t/1e3/4:9.3f} ms/step(4 passes) {c:6d} calls {a:9.1f} us avg  {n[:110]}")
+PY
+tail -1 gpurun_out/prof_top.log | cut -c1-160
