@@ -114,6 +114,36 @@ __global__ __launch_bounds__(512) void k_rand(float* out, int iters, float seed)
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// bf16 twin of k_rand<1>: 8 x 8-bit multipliers instead of 11 x 11 -- does the power limit leave it a higher rate?
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512) void k_rand_bf16(float* out, int iters, float seed) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  bf16x8 fr[8];
+  for (int k = 0; k < 8; ++k)
+    for (int e = 0; e < 8; ++e) {
+      const unsigned hsh = hash32((blockIdx.x * blockDim.x + threadIdx.x) * 64u + k * 8u + e + (unsigned)seed);
+      fr[k][e] = (__bf16)(((int)(hsh & 0xffff) - 32768) * (1.0f / 16384.0f));
+    }
+#define MF(i, ka, kb) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ka], fr[kb], acc[i], 0, 0, 0)
+  for (int it = 0; it < iters; ++it) {
+    MF(0, 2, 4); MF(0, 0, 6); MF(0, 0, 4);
+    MF(1, 2, 5); MF(1, 0, 7); MF(1, 0, 5);
+    MF(2, 3, 4); MF(2, 1, 6); MF(2, 1, 4);
+    MF(3, 3, 5); MF(3, 1, 7); MF(3, 1, 5);
+    const bf16x8 t = fr[0];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) fr[k] = fr[k + 1];
+    fr[7] = t;
+  }
+#undef MF
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename K>
 static void run(const char* name, K kern, int threads, int blocks, int iters, double flop_per_mfma, int accs, float* out, double secs) {
   hipEvent_t e0, e1;
@@ -154,6 +184,7 @@ int main(int argc, char** argv) {
   run("f16 random data, 1 w/SIMD", k_rand<0>, 256, 256, 60000, F16, 12, out, secs);
   run("f16 random data, 2 w/SIMD", k_rand<0>, 512, 256, 30000, F16, 12, out, secs);
   run("f16 random rotating, 2 w/SIMD", k_rand<1>, 512, 256, 30000, F16, 12, out, secs);
+  run("bf16 random rotating, 2 w/SIMD", k_rand_bf16, 512, 256, 30000, F16, 12, out, secs);
   run("f32 32x32x2, 1 wave/SIMD", k_f32<4>, 256, 256, 100000, F32, 4, out, secs);
   run("f32 32x32x2, 2 waves/SIMD", k_f32<4>, 512, 256, 50000, F32, 4, out, secs);
   return 0;
