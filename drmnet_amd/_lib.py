@@ -26,6 +26,7 @@ SYMBOLS = [
     "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_step", "drm_drmnet_sample",
     "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddpm_sample", "drm_randn",
     "drm_profile_enable", "drm_profile_reset", "drm_profile_collect", "drm_unet_set_precision", "drm_set_op_precision",
+    "drm_refmap_workspace_bytes", "drm_refmap_mask_make", "drm_erode_mask",
 ]
 
 
@@ -86,6 +87,11 @@ def lib() -> C.CDLL:
     L.drm_ddim_sample.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_ddpm_sample.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_randn.argtypes = [fp, C.c_size_t, C.c_uint64, C.c_uint64, vp]
+    u8p = vp
+    L.drm_refmap_workspace_bytes.argtypes = [C.c_int64, i32, C.c_float]
+    L.drm_refmap_workspace_bytes.restype = C.c_size_t
+    L.drm_refmap_mask_make.argtypes = [fp, fp, C.c_int64, i32, i32, C.c_float, i32, fp, u8p, vp, C.c_size_t, vp]
+    L.drm_erode_mask.argtypes = [u8p, i32, i32, i32, u8p, vp]
     L.drm_unet_set_precision.argtypes = [vp, i32]
     L.drm_set_op_precision.argtypes = [i32]
     L.drm_profile_enable.argtypes = [i32]

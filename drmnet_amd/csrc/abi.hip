@@ -402,4 +402,25 @@ int drm_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream
   return guarded([&]() -> int { return launch_randn(out, n, seed, offset, static_cast<hipStream_t>(stream)); });
 }
 
+size_t drm_refmap_workspace_bytes(int64_t n, int res, float angle_threshold) {
+  if (n < 0 || res <= 0 || !(angle_threshold >= 0.f)) return 0;
+  return refmap_workspace_bytes(n, res, angle_threshold);
+}
+
+int drm_refmap_mask_make(const float* colors, const float* normals, int64_t n, int channels, int res, float angle_threshold, int min_points,
+                         float* refmap, uint8_t* refmask, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(refmap && refmask && workspace && (n == 0 || (colors && normals)), "drm_refmap_mask_make: null pointer");
+    return launch_refmap_mask_make(colors, normals, n, channels, res, angle_threshold, min_points, refmap, refmask, workspace, workspace_bytes,
+                                   static_cast<hipStream_t>(stream));
+  });
+}
+
+int drm_erode_mask(const uint8_t* mask, int H, int W, int kernel_size, uint8_t* out, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(mask && out, "drm_erode_mask: null pointer");
+    return launch_erode_mask(mask, H, W, kernel_size, out, static_cast<hipStream_t>(stream));
+  });
+}
+
 }  // extern "C"

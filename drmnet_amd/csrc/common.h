@@ -92,6 +92,10 @@ int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* 
                        const float* beta, int N, float* scale, float* shift, hipStream_t s);
 
 // attention (attn.hip): qkv [N][T][3C] -> out [N][T][C]; scores workspace [N][T][T]
+size_t refmap_workspace_bytes(long long n, int res, float thr);
+int launch_refmap_mask_make(const float* colors, const float* normals, long long n, int C, int res, float thr, int min_points, float* refmap,
+                            unsigned char* refmask, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_erode_mask(const unsigned char* mask, int H, int W, int k, unsigned char* out, hipStream_t s);
 int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, bool split = false);
 
 // misc kernels (misc.hip)

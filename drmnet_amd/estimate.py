@@ -1,0 +1,98 @@
+"""Single-image inverse rendering, the reference's scripts/estimate.py on the MI355X path.
+
+    python -m drmnet_amd.estimate --input_img data/sample/image.exr --input_normal data/sample/normal.npy \\
+        --input_mask data/sample/mask.png [--obsnet_base_path configs/obsnet/eval_obsnet.yaml] [--drmnet_base_path ...]
+
+`estimate()` keeps the reference's signature and statement order (scripts/estimate.py:29-107); every stage runs on the GPU:
+mask erosion + refmap_mask_make (csrc/refmap.hip), ObsNet DDIM inpainting and the DRMNet reverse loop (device loops behind
+the C ABI).  The keyword-only `hooks` let tests inject the random draws the reference takes from torch's global generator.
+Rendering the estimated BRDF (Mitsuba, scripts/estimate.py:146-148) is out of scope: the BRDF parameters are printed / saved.
+"""
+from __future__ import annotations
+
+import argparse
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .img2refmap import erode_mask, refmap_mask_make
+
+
+@torch.no_grad()
+def estimate(DRMNet_model, ObsNet_model, input_img: torch.Tensor, input_normal: torch.Tensor, mask: torch.Tensor, tag: str = "sample",
+             erode_kernel_size: int = 5, *, hooks: Optional[dict] = None):
+    hooks = hooks or {}
+    refmap_res = DRMNet_model.ds.size
+    # edge removing (estimate.py:43-50)
+    if erode_kernel_size > 0:
+        mask = erode_mask(mask, erode_kernel_size)
+    # Making refmap from object image (estimate.py:52-58)
+    refmap_est, refmask = refmap_mask_make(input_img[mask], input_normal[mask], res=refmap_res, angle_threshold=np.pi / refmap_res / 2)
+    # Inpainting refmap (estimate.py:63-81)
+    batch = {"tag": [tag], "raw_refmap": refmap_est.permute(2, 0, 1)[None], "raw_refmask": refmask[None]}
+    c, _, _ = ObsNet_model.get_cond_for_predict(batch, noise=hooks.get("cond_noise"))
+    use_ddim = ObsNet_model.ddim_steps is not None
+    extra = {k: hooks[k] for k in ("x_T", "noise") if k in hooks}
+    with ObsNet_model.ema_scope("Plotting"):
+        samples, _ = ObsNet_model.sample_log(cond=c, batch_size=len(batch["tag"]), ddim=use_ddim, ddim_steps=ObsNet_model.ddim_steps,
+                                             eta=ObsNet_model.ddim_eta, **extra)
+    inpaint_sample = ObsNet_model.ds.rescale(ObsNet_model.decode_first_stage(samples))[0]
+    # Inverse Rendering (estimate.py:86-104)
+    batch = {"tag": [tag], "LrK": inpaint_sample[None]}
+    LrK, _, illnet_c, refnet_c, _ = DRMNet_model.get_input_for_predict(batch)
+    loop_extra = {k: hooks[k] for k in ("noise0", "step_noise") if k in hooks}
+    with DRMNet_model.ema_scope():
+        samples, zK_est, _ = DRMNet_model.p_sample_loop(LrK, illnet_c, refnet_c, verbose=False, **loop_extra)
+    Lr0_sample = DRMNet_model.ds.rescale(DRMNet_model.decode_first_stage(samples))[0].clip(0)
+    zK_est = zK_est[0]
+    if DRMNet_model.refmap_input_scaler is not None:
+        Lr0_sample = Lr0_sample / DRMNet_model.normalizing_scale[0]
+    if "stages" in hooks:  # tests look at the intermediate products
+        hooks["stages"].update(mask=mask, refmap=refmap_est, refmask=refmask, cond=c, inpaint=inpaint_sample, LrK=LrK)
+    return Lr0_sample, zK_est
+
+
+def main(argv=None):
+    from . import file_io
+    from .config import instantiate_from_config, load_config
+    from .transform import hdr2ldr
+
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--input_img", type=Path, help="The path of HDR image for an object (.exr)")
+    parser.add_argument("--input_normal", type=Path, help="The path of normal map for an object (.npy)")
+    parser.add_argument("--input_mask", type=Path, help="The path of mask for an object (.png)", default=None)
+    parser.add_argument("--obsnet_base_path", type=Path, help="the config path for obsnet", default=Path("./configs/obsnet/eval_obsnet.yaml"))
+    parser.add_argument("--drmnet_base_path", type=Path, help="the config path for drmnet", default=Path("./configs/drmnet/eval_drmnet.yaml"))
+    parser.add_argument("--output_dir", type=Path, help="the output directory", default=Path("./outputs/"))
+    args = parser.parse_args(argv)
+
+    obsnet_base_config = load_config(args.obsnet_base_path)
+    obsnet_model = instantiate_from_config(obsnet_base_config["model"]).cuda()
+    obsnet_model.ds = instantiate_from_config(obsnet_base_config["data"]["params"]["predict"])
+    drmnet_base_config = load_config(args.drmnet_base_path)
+    drmnet_model = instantiate_from_config(drmnet_base_config["model"]).cuda()
+    drmnet_model.ds = instantiate_from_config(drmnet_base_config["data"]["params"]["predict"])
+
+    input_img = file_io.load_exr(args.input_img, as_torch=True).cuda()
+    input_normal = torch.from_numpy(np.load(args.input_normal)).cuda()
+    normal_mask = torch.linalg.norm(input_normal, dim=-1) > 0.5
+    if args.input_mask is not None:
+        input_mask = file_io.load_png(args.input_mask, as_torch=True).cuda()
+        if input_mask.ndim == 3:
+            input_mask = input_mask[:, :, 0]
+        mask = torch.logical_and(input_mask, normal_mask)
+    else:
+        mask = normal_mask
+
+    Lr0_sample, zK_est = estimate(drmnet_model, obsnet_model, input_img, input_normal, mask)
+    envmap_est = drmnet_model.r0toenvmap(Lr0_sample[None], (drmnet_model.image_size, drmnet_model.image_size * 2))[0]  # [H, W, 3]
+    args.output_dir.mkdir(exist_ok=True)
+    file_io.save_png(args.output_dir / "sample_env.png", hdr2ldr(envmap_est.cpu().numpy()))
+    np.save(args.output_dir / "sample_brdf.npy", zK_est.cpu().numpy())
+    print("estimated BRDF parameters", dict(zip(drmnet_model.brdf_param_names, zK_est.tolist())))
+
+
+if __name__ == "__main__":
+    main()

@@ -172,6 +172,22 @@ int drm_profile_collect(double* ms, double* flops, double* bytes, int64_t* launc
 /* Standard-normal fill from the library's Philox4x32-10 stream (throughput mode noise source). */
 int drm_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
 
+/* Object image -> reflectance map, the step in front of the samplers (reference: refmap_mask_make,
+ * utils/img2refmap.py:6-37, with xyz2thetaphi(normal = [0,1,0], tangent = [-1,0,0]), utils/transform.py:55-89).
+ *   colors  [n][channels], normals [n][3]: the object pixels (fp32, device).  res: the map is res x res texels over
+ *   (theta, phi) in (0, pi)^2.  A texel takes the colour of the pixel whose colour SUM is the lower median
+ *   (torch.nanmedian) among the pixels with max(|theta - theta_i|, |phi - phi_j|) <= angle_threshold (fp32 compare);
+ *   fewer than min_points such pixels, or none with a non-NaN sum, leaves it zero / unmasked.
+ *   refmap [res][res][channels] fp32, refmask [res][res] uint8 (0/1).
+ * Synchronises the stream once (capacity check of the binning lists). */
+size_t drm_refmap_workspace_bytes(int64_t n, int res, float angle_threshold);
+int drm_refmap_mask_make(const float* colors, const float* normals, int64_t n, int channels, int res, float angle_threshold, int min_points,
+                         float* refmap, uint8_t* refmask, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Mask erosion of scripts/estimate.py:43-50: a mask pixel is dropped when a non-mask pixel lies inside the disk
+ * footprint of diameter kernel_size around it (zero "same" padding: the image border does not erode).  uint8 0/1, [H][W]. */
+int drm_erode_mask(const uint8_t* mask, int H, int W, int kernel_size, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -317,7 +317,168 @@ def make_obsnet_samplers():
         refddim.noise_like, refddpm.noise_like = o1, o2
 
 
+def make_refmap():
+    """refmap_mask_make (utils/img2refmap.py:6-37) and the mask erosion of scripts/estimate.py:43-50 on the reference's own
+    data/sample inputs.  The three sample files are DATA and are copied next to the fixtures (tests/golden/sample/); the EXR
+    is decoded with drmnet_amd/file_io.py (no OpenCV in this image) -- the decoded array is what the reference function gets."""
+    import shutil
+
+    rh.install_stubs()
+    from utils.img2refmap import refmap_mask_make  # the reference function
+
+    sys.path.insert(0, ROOT)
+    from drmnet_amd import file_io
+
+    src = "/root/reference/data/sample"
+    dst = os.path.join(GOLD, "sample")
+    os.makedirs(dst, exist_ok=True)
+    for f in ("image.exr", "normal.npy", "mask.png"):
+        shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+        os.chmod(os.path.join(dst, f), 0o644)
+    img = file_io.load_exr(os.path.join(dst, "image.exr"), as_torch=True)
+    normal = torch.from_numpy(np.load(os.path.join(dst, "normal.npy")))
+    normal_mask = torch.linalg.norm(normal, dim=-1) > 0.5
+    input_mask = file_io.load_png(os.path.join(dst, "mask.png"), as_torch=True)
+    mask0 = torch.logical_and(input_mask, normal_mask)  # estimate.py:128-136
+    # estimate.py:43-50, verbatim semantics on CPU
+    k = 5
+    inv_mask = ~mask0
+    kernel = torch.stack(torch.meshgrid(*torch.arange(k).expand(2, -1), indexing="ij"))
+    kernel = kernel + 0.5
+    kernel = torch.linalg.norm(kernel - k / 2, axis=0) <= k / 2
+    kernel = kernel[None, None].float()
+    inv_mask = torch.nn.functional.conv2d(inv_mask[None, None].float(), kernel, padding="same").bool()[0, 0]
+    mask = torch.logical_and(mask0, ~inv_mask)
+    cases = {"128": (128, np.pi / 128 / 2), "16": (16, np.pi / 16 / 2), "32wide": (32, np.pi / 40)}
+    out = {"mask0": mask0.numpy(), "mask_eroded": mask.numpy()}
+    for tag, (res, thr) in cases.items():
+        refmap, refmask = refmap_mask_make(img[mask], normal[mask], res=res, angle_threshold=thr)
+        out[f"refmap_{tag}"] = refmap.numpy()
+        out[f"refmask_{tag}"] = refmask.numpy()
+        out[f"res_{tag}"] = np.int64(res)
+        out[f"thr_{tag}"] = np.float64(thr)
+        print(f"  refmap {tag}: {int(refmask.sum())} texels of {res * res} set, n = {int(mask.sum())} pixels")
+    save("refmap_sample", **out)
+
+
+def make_estimate_chain():
+    """scripts/estimate.py:29-107 + :138-145 end to end on data/sample with 16x16 tiny networks (weights by rule, no
+    checkpoint): erosion -> refmap_mask_make -> ObsNet cond transform -> DDIM-50 (eta = 1, noise injected) -> rescale ->
+    DRMNet input transform -> DRMNet reverse loop (noise injected) -> rescale / clip / un-normalise -> r0toenvmap -> hdr2ldr.
+    estimate() itself hard-codes .cuda() / cuda.synchronize(); its statements are executed here in the same order on CPU."""
+    import ldm.models.diffusion.ddim as refddim
+    import models.drmnet as refdrm
+    from dataset.basedataset import BaseDataset
+    from utils.img2refmap import refmap_mask_make
+    from utils.tonemap import hdr2ldr
+
+    sys.path.insert(0, ROOT)
+    from drmnet_amd import file_io
+
+    res = 16
+    # Random-weight networks are not denoisers: with the production noise schedule (alpha_bar_T ~ 1e-20) the DDIM iterate
+    # explodes to the rescale clamp (1e20) and the rest of the chain is inf/NaN.  The chain fixture therefore uses a gentle
+    # schedule and a damped ObsNet head so every stage stays finite and O(1); the schedules proper are pinned elsewhere.
+    obs_sched = dict(linear_start=1e-5, linear_end=2e-4)
+    obs_out_scale = 0.05
+    _, OBS, DDIM, _ = rh.ref_classes()
+    ocfg_m = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["model"]["params"]
+    ocfg_m.pop("ckpt_path")
+    ocfg_m["unet_config"] = {"target": ocfg_m["unet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    ocfg_m.update(image_size=16, use_ema=False, **obs_sched)
+    obs = OBS(**ocfg_m).eval()
+    synth.load_synth(obs.model.diffusion_model, 21)
+    with torch.no_grad():
+        obs.model.diffusion_model.out[2].weight.mul_(obs_out_scale)
+        obs.model.diffusion_model.out[2].bias.mul_(obs_out_scale)
+    drm = tiny_drmnet(gamma=0.9, epsilon=1.0, max_timesteps=17)
+    head = drm.refnet_model.diffusion_model.out[3]
+    head_bias = torch.tensor([0.95, 0.9, 0.97, 0.92, 0.05, 0.9])
+    ill_out_scale = 0.05  # damped IllNet head: the residual updates stay small, the map stays inside the rescale clamp
+    with torch.no_grad():
+        head.weight.mul_(10.0)
+        head.bias.copy_(head_bias)
+        drm.illnet_model.diffusion_model.out[2].weight.mul_(ill_out_scale)
+        drm.illnet_model.diffusion_model.out[2].bias.mul_(ill_out_scale)
+    ocfg = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["data"]["params"]["predict"]["params"]
+    dcfg = rh.load_yaml_params("configs/drmnet/eval_drmnet.yaml")["data"]["params"]["predict"]["params"]
+    obs.ds = BaseDataset(**dict(ocfg, size=res))
+    drm.ds = BaseDataset(**dict(dcfg, size=res))
+
+    d = os.path.join(GOLD, "sample")
+    input_img = file_io.load_exr(os.path.join(d, "image.exr"), as_torch=True)
+    input_normal = torch.from_numpy(np.load(os.path.join(d, "normal.npy")))
+    normal_mask = torch.linalg.norm(input_normal, dim=-1) > 0.5
+    mask = torch.logical_and(file_io.load_png(os.path.join(d, "mask.png"), as_torch=True), normal_mask)
+    k = 5
+    inv_mask = ~mask
+    kernel = torch.stack(torch.meshgrid(*torch.arange(k).expand(2, -1), indexing="ij")) + 0.5
+    kernel = (torch.linalg.norm(kernel - k / 2, axis=0) <= k / 2)[None, None].float()
+    inv_mask = torch.nn.functional.conv2d(inv_mask[None, None].float(), kernel, padding="same").bool()[0, 0]
+    mask = torch.logical_and(mask, ~inv_mask)
+    refmap_est, refmask = refmap_mask_make(input_img[mask], input_normal[mask], res=res, angle_threshold=np.pi / res / 2)
+    batch = {"tag": ["sample"], "raw_refmap": refmap_est.permute(2, 0, 1)[None], "raw_refmask": refmask[None]}
+    with torch.no_grad():
+        c, _, _ = obs.get_cond_for_predict(batch)
+    g = gen(77)
+    x_T = torch.randn((1, 3, res, res), generator=g)
+    noise = torch.randn((50, 1, 3, res, res), generator=g)
+    ctr = {"i": 0}
+
+    def noise_like(shape, device, repeat=False):
+        out = noise[ctr["i"]]
+        ctr["i"] += 1
+        return out
+
+    o1 = refddim.noise_like
+    refddim.noise_like = noise_like
+    try:
+        with torch.no_grad():
+            samples, _ = DDIM(obs).sample(obs.ddim_steps, 1, (obs.channels, obs.image_size, obs.image_size), c, verbose=False,
+                                          log_every_t=max(obs.log_every_t * obs.ddim_steps // obs.num_timesteps, 1), eta=obs.ddim_eta, x_T=x_T)
+    finally:
+        refddim.noise_like = o1
+    inpaint_sample = obs.ds.rescale(obs.decode_first_stage(samples))[0]
+    batch = {"tag": ["sample"], "LrK": inpaint_sample[None]}
+    LrK, _, illnet_c, refnet_c, _ = drm.get_input_for_predict(batch)
+    T = 17
+    noise0 = torch.randn(LrK.shape, generator=g)
+    step_noise = torch.randn((T,) + tuple(LrK.shape), generator=g)
+    state = {"call": 0, "step": 0}
+    orig = torch.randn_like
+
+    def randn_like(t, **kw):
+        if state["call"] == 0:
+            state["call"] += 1
+            return noise0.clone()
+        out = step_noise[state["step"]]
+        state["step"] += 1
+        return out
+
+    refdrm.torch.randn_like = randn_like
+    try:
+        with torch.no_grad():
+            samples2, zK_est, K = drm.p_sample_loop(LrK, illnet_c, refnet_c, verbose=False)
+    finally:
+        refdrm.torch.randn_like = orig
+    Lr0_sample = drm.ds.rescale(drm.decode_first_stage(samples2))[0].clip(0)
+    if drm.refmap_input_scaler is not None:
+        Lr0_sample = Lr0_sample / drm.normalizing_scale[0]
+    envmap = drm.r0toenvmap(Lr0_sample[None], (drm.image_size, drm.image_size * 2))[0]
+    ldr = hdr2ldr(envmap.cpu().numpy())
+    print(f"  chain: refmask {int(refmask.sum())}/{res * res}, K = {K.tolist()}, zK = {zK_est[0].tolist()}, env {tuple(envmap.shape)}")
+    save("estimate_chain", refmap=refmap_est, refmask=refmask, cond=c, x_T=x_T, noise=noise, inpaint=inpaint_sample, LrK=LrK, noise0=noise0,
+         step_noise=step_noise, K=K, zK=zK_est, Lr0=Lr0_sample, envmap=envmap, ldr=ldr, head_bias=head_bias, head_w_scale=10.0,
+         gamma=0.9, epsilon=1.0, max_timesteps=17, delta=0.025, obs_out_scale=obs_out_scale, ill_out_scale=ill_out_scale, obs_linear_start=obs_sched["linear_start"],
+         obs_linear_end=obs_sched["linear_end"])
+    for k_, v_ in (("inpaint", inpaint_sample), ("Lr0", Lr0_sample), ("envmap", envmap)):
+        assert torch.isfinite(v_).all(), k_
+        print(f"  {k_}: min {float(v_.min()):.3e} max {float(v_.max()):.3e}")
+
+
 STEPS = {
+    "refmap": lambda oa: make_refmap(),
+    "estimate_chain": lambda oa: make_estimate_chain(),
     "manifests": lambda oa: make_manifests(oa),
     "primitives": lambda oa: make_primitives(oa),
     "brdf": lambda oa: make_brdf_schedule(),
