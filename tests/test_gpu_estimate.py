@@ -92,10 +92,10 @@ def test_estimate_chain_vs_reference_trace(precision):
     print(f"estimate chain ({precision}):", {k: f"{v:.2e}" for k, v in e.items()}, "zK", zK.tolist(), "steps", drm.last_steps)
     assert np.isfinite(g["Lr0"]).all() and np.isfinite(g["envmap"]).all()
     assert e["cond"] < 1e-6
-    # 10 ** x rescales (BaseDataset.rescale) turn the samplers' 1e-4 tolerance into ~ln(10) * range * 1e-4 relative
-    assert e["inpaint"] < 2e-3 and e["LrK"] < 1e-3 and e["Lr0"] < 2e-3 and e["envmap"] < 2e-3
+
+    assert e["inpaint"] < 1e-4 and e["LrK"] < 1e-4 and e["Lr0"] < 1e-4 and e["envmap"] < 1e-4  # the north-star tolerance, end to end
     log_err = np.abs(np.log10(Lr0.cpu().numpy() + 0.1) - np.log10(g["Lr0"] + 0.1)).max()
-    assert log_err < 1e-3, log_err
+    assert log_err < 1e-4, log_err
     assert drm.last_steps == int(g["K"][0])
     assert np.allclose(zK.cpu().numpy(), g["zK"][0], atol=1e-5, equal_nan=True)
     assert np.abs(ldr.astype(np.float64) - g["ldr"]).max() < 5e-3
