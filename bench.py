@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim"])
-    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"],
+    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "f16"],
                     help="conv arithmetic: f16x3 (default) = every fp32 operand split into fp16 hi+lo, 3 MFMAs per product, fp32 "
                          "accumulate: passes the SAME parity tolerances as fp32 (tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -234,11 +234,14 @@ def main():
         if n[0] > 0:
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
             split = args.precision == "f16x3"
-            peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            plain = args.precision == "f16"  # reduced precision (BASELINE configs[2]); never the default
+            peak = F16_MFMA_PEAK_TFLOPS if (split or plain) else FP32_MFMA_PEAK_TFLOPS
             kname = ("conv_igemm_split_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp16 hi/lo x3 v_mfma_f32_32x32x16_f16, fp32 accumulate; "
                      "achieved counts ALGORITHMIC FLOPs, the matrix cores execute 3x that)") if split else \
                 "conv_igemm_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp32 v_mfma_f32_32x32x2_f32)"
             kname = kname.replace("conv_igemm_split_kernel", "conv_split2_kernel")
+            if plain:
+                kname = "conv_split2_kernel<9,...,TERMS=1> (fused GroupNorm+SiLU+conv3x3, fp16 operands, one v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)"
             roofline = {"bound": "mfma", "kernel": kname,
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": None, "launches": int(n[0]), "avg_launch_ms": round(ms[0] / n[0], 4),
@@ -248,6 +251,10 @@ def main():
                 roofline["executed_mfma_tflops"] = round(3 * ach, 2)
                 roofline["executed_frac_of_f16_peak"] = round(3 * ach / peak, 4)
                 roofline["fp32_mfma_peak_for_reference"] = FP32_MFMA_PEAK_TFLOPS
+                # what the matrix pipes sustain under the socket power limit on operands that look like data
+                # (tools/mfma_peak.hip, profiles/r01_mfma_power_limit.json): 1.43-1.67 PFLOP/s, not the 2.5 PFLOP/s of the data sheet
+                roofline["power_limited_f16_mfma_tflops_measured"] = [1430.0, 1670.0]
+                roofline["executed_frac_of_power_limited_peak"] = [round(3 * ach / 1670.0, 4), round(3 * ach / 1430.0, 4)]
             # HBM traffic is a PMC quantity: it cannot be read from inside this process, so it is taken from the committed
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/), dominant variant, per launch
             try:
@@ -274,7 +281,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 via split f16x3 MFMA (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)",
+            "dtype": {"fp32": "f32", "f16x3": "f32 via split f16x3 MFMA (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)",
+                      "f16": "f16 operands, fp32 accumulate (REDUCED PRECISION, ~1e-3 rel-L2: not the headline configuration)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": args.batch, "refmap": f"3x{args.height}x{args.width}",
                        "weights": "seeded synthetic (no checkpoint offline)", "parallelism": f"batch-sharded x{world}, no collective",

@@ -75,7 +75,7 @@ int g_op_precision = PREC_FP32;  // arithmetic used by the drm_op_* entry points
 
 // packs one conv weight for the current op precision; `slot` = 64-float scale slot (2^k, 2^-k), `scratch` = 1 uint
 int pack_for_ops(const float* w, float* dst, float* slot, float* scratch, int cout, int cin, int taps, int coutp, int cinp, hipStream_t s) {
-  if (g_op_precision == PREC_F16X3 && cinp % 32 == 0)
+  if (g_op_precision != PREC_FP32 && cinp % 32 == 0)
     return launch_pack_conv_weight_split(w, dst, slot, reinterpret_cast<unsigned*>(scratch), cout, cin, taps, coutp, cinp, s);
   return launch_pack_conv_weight(w, dst, cout, cin, taps, coutp, cinp, s);
 }
@@ -375,14 +375,16 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
 
 int drm_unet_set_precision(drm_unet* net, int precision) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(net && (precision == PREC_FP32 || precision == PREC_F16X3), "precision must be 0 (fp32 MFMA) or 1 (split fp16 x3)");
+    DRM_REQUIRE(net && (precision == PREC_FP32 || precision == PREC_F16X3 || precision == PREC_F16),
+                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3) or 2 (plain fp16 operands)");
     net->net.precision = precision;
     return DRM_OK;
   });
 }
 int drm_set_op_precision(int precision) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(precision == PREC_FP32 || precision == PREC_F16X3, "precision must be 0 (fp32 MFMA) or 1 (split fp16 x3)");
+    DRM_REQUIRE(precision == PREC_FP32 || precision == PREC_F16X3 || precision == PREC_F16,
+                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3) or 2 (plain fp16 operands)");
     g_op_precision = precision;
     return DRM_OK;
   });

@@ -136,7 +136,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, float4&
   lo = l.f4;
 }
 
-template <bool BT>
+template <bool BT, int TERMS>
 __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm, int M,
                                                        int Ncols, int K, int lda, int ldb, int ldc, long long sA, long long sB, long long sC,
                                                        float alpha, float a_scale) {
@@ -193,8 +193,10 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
       al.f4 = As[(4 + oct) * 64 + wm * 32 + r];
       bh.f4 = Bs[oct * 64 + wn * 32 + r];
       bl.f4 = Bs[(4 + oct) * 64 + wn * 32 + r];
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h8, bh.h8, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bl.h8, acc, 0, 0, 0);
+      if (TERMS == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h8, bh.h8, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bl.h8, acc, 0, 0, 0);
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bh.h8, acc, 0, 0, 0);
     }
     __syncthreads();
@@ -229,15 +231,19 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
   for (int i = lane; i < T; i += 64) p[i] *= inv;
 }
 
-int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, bool split) {
+int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms) {
+  bool split = terms != 0;
   DRM_REQUIRE(C % 4 == 0 && T > 0 && N > 0, "attention shape");
   const float alpha = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, applied once to the dot product
   const int tb = (T + 63) / 64;
   prof_tag(N, T, 1, C, C);
   ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C + 4.0 * T * T), s);
   split = split && (C % 32 == 0) && (T % 32 == 0);
-  if (split)
-    hipLaunchKernelGGL(bgemm64s_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
+  if (split && terms == 1)
+    hipLaunchKernelGGL((bgemm64s_kernel<true, 1>), dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
+                       (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha, 1.0f);
+  else if (split)
+    hipLaunchKernelGGL((bgemm64s_kernel<true, 3>), dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
                        (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha, 1.0f);
   else
     hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
@@ -246,8 +252,11 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
   const long long rows = (long long)N * T;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, scores, rows, T);
   DRM_HIP_CHECK(hipGetLastError());
-  if (split)  // probabilities are scaled by 2^12 before the fp16 split (largest 4096, smallest normal 2^-26)
-    hipLaunchKernelGGL(bgemm64s_kernel<false>, dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
+  if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
+    hipLaunchKernelGGL((bgemm64s_kernel<false, 1>), dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
+                       (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
+  else if (split)
+    hipLaunchKernelGGL((bgemm64s_kernel<false, 3>), dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
                        (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
   else
     hipLaunchKernelGGL(bgemm64_kernel<false>, dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,

@@ -65,6 +65,7 @@ struct ConvArgs {
   float* out = nullptr;             // NHWC [N,H,W,Cout], or NCHW [N,cout_valid,H,W] if out_nchw
   int out_nchw = 0, cout_valid = 0;
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
+  int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 1 = plain fp16 operands
   unsigned long long* trace = nullptr;  // experiment build only: per-wave phase cycle counters
   int dbg = 0;                         // experiment switches (DRM_DBG env): 1 skip B reloads, 2 skip A reloads, 4 skip MFMA, 8 skip barriers
   double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)
@@ -77,7 +78,7 @@ bool conv_split_fuses_stats();  // true when the active split kernel accumulates
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);
 int launch_pack_conv_weight_split(const float* w, float* packed, float* scales, unsigned* scratch, int Cout, int Cin, int taps, int CoutP,
                                   int CinP, hipStream_t s);
-enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1 };
+enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 // repack PyTorch conv weight [Cout][Cin][kh][kw] -> [taps][CinP/4][CoutP][4] (zero padded)
 int launch_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int taps, int CoutP, int CinP, hipStream_t s);
 size_t packed_conv_weight_floats(int taps, int CoutP, int CinP);
@@ -96,7 +97,8 @@ size_t refmap_workspace_bytes(long long n, int res, float thr);
 int launch_refmap_mask_make(const float* colors, const float* normals, long long n, int C, int res, float thr, int min_points, float* refmap,
                             unsigned char* refmask, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_erode_mask(const unsigned char* mask, int H, int W, int k, unsigned char* out, hipStream_t s);
-int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, bool split = false);
+// terms: 0 = fp32 MFMA, 3 = fp16 hi/lo split, 1 = plain fp16 operands
+int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms = 0);
 
 // misc kernels (misc.hip)
 int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s);

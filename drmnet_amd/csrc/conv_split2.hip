@@ -47,7 +47,7 @@ namespace drm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
 struct S2Cfg {
   static constexpr int KC = 32;
   static constexpr int NW = WM * WN;  // waves
@@ -77,8 +77,9 @@ struct S2Cfg {
   static constexpr int A_SLOTS = (HPI * OCT + TPI - 1) / TPI;
   static constexpr int A1_F4 = 8 * HP;                       // one activation tile image
   static constexpr int A_F4 = A_COPIES * A1_F4;  // 1x1: double-buffered (a new tile every step)
-  static constexpr int B_F4 = 8 * BN;
-  static constexpr int B_PER = B_F4 / NTHR;  // LDS-DMA instructions per wave per weight tile
+  static constexpr int B_F4 = 8 * BN;                            // LDS image of one tap's weight tile (hi and lo planes)
+  static constexpr int B_DMA_F4 = (TERMS == 3 ? 8 : 4) * BN;      // what is fetched: the single-product mode needs the hi plane only
+  static constexpr int B_PER = (B_DMA_F4 + NTHR - 1) / NTHR;      // LDS-DMA instructions per (issuing) wave per weight tile
   static constexpr int NG = TAPS / TPS;      // pipeline steps ("groups" of TPS taps) per 32-channel chunk
   static constexpr int G_PER = TPS * B_PER;  // LDS-DMA instructions per wave per group
   static constexpr int G_F4 = TPS * B_F4;    // float4 per group in the ring
@@ -101,7 +102,8 @@ struct S2Cfg {
     }
   }
   static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
-  static_assert(B_F4 % NTHR == 0 && B_PER >= 1, "every wave issues the same number of LDS-DMA loads per tile");
+  static_assert(B_DMA_F4 % 64 == 0 && B_PER >= 1, "whole 1-KiB LDS-DMA instructions; a wave issues B_PER of them or none");
+  static_assert(TERMS == 3 || TERMS == 1, "3 = fp16 hi/lo split (fp32 accuracy), 1 = plain fp16 operands");
   static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
   static_assert(R >= 2, "ring needs >= 2 slots");
 };
@@ -156,9 +158,9 @@ struct TilePos {
   int n0, ty0, tx0, co0;
 };
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a) {
-  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS>;
+  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
   extern __shared__ float4 lds[];
   float4* As = lds;                                                   // [hl 2][s 2][h 2][HP]  16-byte entries
   float4* Bs = lds + C::A_F4;                                         // R x TPS x [hl 2][s 2][h 2][BN]
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         const int hpl = lidx / C::OCT;
         const int pixel = l_img * C::HPIP + (hpl / C::WT) * C::WTP + (hpl % C::WT);
         Ad[l_o * C::HP + pixel] = hi.f4;
-        Ad[(4 + l_o) * C::HP + pixel] = lo.f4;
+        if (TERMS == 3) Ad[(4 + l_o) * C::HP + pixel] = lo.f4;
       }
     }
   };
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     const int tap = g * TPS + u;
     const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nchunks + chunk) * 8) * a.Cout + co0;
     const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
+    if (base >= C::B_DMA_F4) return;           // (single-product mode on narrow tiles: the upper waves have nothing to fetch)
     const int idx = base + lane;
     const int seg = idx / C::BN, co = idx % C::BN;
     glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
@@ -322,6 +325,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
       for (int j = 0; j < C::B_PER; ++j) {
         const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
+        if (base >= C::B_DMA_F4) continue;
         const int idx = base + lane;
         const int seg = idx / C::BN, co = idx % C::BN;
         glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
@@ -424,20 +428,22 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
             ah[i].f4 = Ab[seg * C::HP + a_base[i] + tapoff];
-            al[i].f4 = Ab[(4 + seg) * C::HP + a_base[i] + tapoff];
+            if (TERMS == 3) al[i].f4 = Ab[(4 + seg) * C::HP + a_base[i] + tapoff];
           }
 #pragma unroll
           for (int c = 0; c < NT; ++c) {
             bh[c].f4 = Bc[seg * C::BN + b_base[c]];
-            bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
+            if (TERMS == 3) bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
           }
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int c = 0; c < NT; ++c) {
-            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
+            if (TERMS == 3) {
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
+            }
             acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
             if (i == 0 && c == 0) {
               // memory-side instructions of this step go out here, a few at a time, behind MFMAs that keep the pipe busy
@@ -703,10 +709,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   wait_vmcnt<0>();  // drain the tail DMAs before the workgroup's LDS can be re-assigned
 }
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
 static int launch_s2(const ConvArgs& a, hipStream_t s) {
-  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS>;
-  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS>;
+  using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
+  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
   const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
   static_assert(C::LDS_F4 * 16 <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
@@ -770,7 +776,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
 }
 
 // 256-pixel x {128, 64}-channel tiles on 8 waves, 128-pixel x {64, 32}-channel tiles on 4 waves
-template <int TAPS, int TH, int TW, int TH4, int TW4>
+template <int TAPS, int TH, int TW, int TH4, int TW4, int TERMS>
 static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   // Deep U-Net levels (4x8 .. 8x16 maps) have few GEMM rows: with 256x128 tiles they launch far fewer workgroups than
   // the chip has CUs.  Shrink the tile (128 rows, then 64 / 32 channels) until the grid covers the 256 CUs.
@@ -783,41 +789,45 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   constexpr bool big_ok = (TAPS == 1) || (TH >= 8);
   static const int no_db = getenv("DRM_S2_DB") ? 0 : 1;  // A/B switch: DRM_S2_DB=1 selects the double-buffered halo tile variants
   if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) {
-    if constexpr (TAPS == 9 && big_ok) {
+    if constexpr (TAPS == 9 && big_ok && TERMS == 3) {
       if constexpr (S2Cfg<TAPS, TH, TW, 4, 2, 2, 2, 4, 1>::DB) {
-        if (!no_db) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4, 1>(a, s);
+        if (!no_db) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4, 1, TERMS>(a, s);
       }
     }
-    if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS>(a, s);
-    else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1>(a, s);
+    if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
+    else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
   }
   if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) {
-    if constexpr (TAPS == 9 && big_ok) {
+    if constexpr (TAPS == 9 && big_ok && TERMS == 3) {
       if constexpr (S2Cfg<TAPS, TH, TW, 4, 2, 2, 1, 4, 1>::DB) {
-        if (!no_db) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, 4, 1>(a, s);
+        if (!no_db) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, 4, 1, TERMS>(a, s);
       }
     }
-    if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS>(a, s);
-    else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS>(a, s);
+    if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS, TERMS>(a, s);
+    else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
   }
-  if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS>(a, s);
-  return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS>(a, s);
+  if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
+  return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS, TERMS>(a, s);
 }
 
-template <int TAPS>
+template <int TAPS, int TERMS>
 static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
-  if (a.H % 16 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 16, 16, 8, 16>(a, s);
-  if (a.H % 8 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 8, 16, 8, 16>(a, s);
-  if (a.H % 8 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 8, 8, 8, 8>(a, s);
-  if (a.H % 4 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 4, 8, 4, 8>(a, s);
-  if (a.H % 4 == 0 && a.W % 4 == 0) return dispatch_s2_bn<TAPS, 4, 4, 4, 4>(a, s);
+  if (a.H % 16 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 16, 16, 8, 16, TERMS>(a, s);
+  if (a.H % 8 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 8, 16, 8, 16, TERMS>(a, s);
+  if (a.H % 8 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 8, 8, 8, 8, TERMS>(a, s);
+  if (a.H % 4 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 4, 8, 4, 8, TERMS>(a, s);
+  if (a.H % 4 == 0 && a.W % 4 == 0) return dispatch_s2_bn<TAPS, 4, 4, 4, 4, TERMS>(a, s);
   set_error("conv: feature map " + std::to_string(a.H) + "x" + std::to_string(a.W) + " is not a multiple of 4x4");
   return DRM_ERR_INVALID;
 }
 
 int launch_conv_split2(const ConvArgs& a, hipStream_t s) {
-  if (a.taps == 9) return dispatch_s2_tile<9>(a, s);
-  return dispatch_s2_tile<1>(a, s);
+  if (a.terms == 1) {  // plain fp16 operands, one MFMA per product (DRM_PREC_F16)
+    if (a.taps == 9) return dispatch_s2_tile<9, 1>(a, s);
+    return dispatch_s2_tile<1, 1>(a, s);
+  }
+  if (a.taps == 9) return dispatch_s2_tile<9, 3>(a, s);
+  return dispatch_s2_tile<1, 3>(a, s);
 }
 
 }  // namespace drm

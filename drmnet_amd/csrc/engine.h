@@ -132,7 +132,8 @@ struct Ctx {
   int N;
   int precision = PREC_FP32;
   bool dry() const { return ar->dry; }
-  bool split() const { return precision == PREC_F16X3; }
+  bool split() const { return precision == PREC_F16X3 || precision == PREC_F16; }
+  int terms() const { return precision == PREC_F16 ? 1 : 3; }
 };
 Act new_act(Ctx& c, int C, int H, int W);
 int ensure_moments(Ctx& c, Act& a);

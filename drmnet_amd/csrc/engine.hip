@@ -207,7 +207,7 @@ int UNet::load(const float* const* ptrs, int count, hipStream_t s) {
     DRM_REQUIRE(ptrs[i] != nullptr, "null parameter pointer for " + p.name);
     if (p.kind == PK_COPY) {
       DRM_HIP_CHECK(hipMemcpyAsync(wbuf + p.dst, ptrs[i], p.count * sizeof(float), hipMemcpyDeviceToDevice, s));
-    } else if (precision == PREC_F16X3 && p.cinp % 32 == 0) {
+    } else if (precision != PREC_FP32 && p.cinp % 32 == 0) {  // both fp16 modes use the pre-split, pre-scaled image
       DRM_TRY(launch_pack_conv_weight_split(ptrs[i], wbuf + p.dst, wbuf + p.scale_dst, reinterpret_cast<unsigned*>(wbuf + scratch_off), p.cout,
                                             p.cin, p.taps, p.coutp, p.cinp, s));
     } else {
@@ -244,6 +244,7 @@ int ensure_moments(Ctx& c, Act& a) {
 int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_for) {
   if (c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0) {
     a.w_inv_scale = Wb + scale_off + 1;
+    a.terms = c.terms();
     if (stats_for && !a.out_nchw && conv_split_fuses_stats()) {
       if (!stats_for->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(stats_for->mom, 0, (size_t)c.N * stats_for->C * sizeof(double2), c.s));
       a.stat_out = stats_for->mom;
@@ -325,7 +326,7 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
     a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
     a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.taps = 1; a.Cout = 3 * C; a.out = qkv;
     DRM_TRY(run_conv(c, a, Wb, l.qkv_s));
-    DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split()));
+    DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split() ? c.terms() : 0));
     ConvArgs p;
     p.src0 = att; p.C0 = C; p.N = c.N; p.H = H; p.W = W;
     p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.taps = 1; p.Cout = C; p.res = x.p; p.out = out.p;

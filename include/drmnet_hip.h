@@ -69,6 +69,10 @@ int drm_unet_load_params(drm_unet* net, const float* const* ptrs, int count, voi
  * drm_op_* entry points. */
 #define DRM_PREC_FP32 0
 #define DRM_PREC_F16X3 1
+/*   2 = DRM_PREC_F16  : REDUCED PRECISION.  Operands rounded to fp16 (weights after the same power-of-two pre-scaling), one
+ *       f16 MFMA per product, fp32 accumulation, fp32 activations in HBM.  ~1e-3 rel-L2 on the full networks -- outside the
+ *       1e-4 contract of the two modes above; offered for BASELINE configs[2] (the reference's reduced-precision sampling). */
+#define DRM_PREC_F16 2
 int drm_unet_set_precision(drm_unet* net, int precision);
 int drm_set_op_precision(int precision);
 

@@ -120,3 +120,22 @@ def test_split_full_width_nets_vs_reference_golden(dev, name, cfg, kind):
     assert rel_l2(out32.cpu(), gd["out"]) < NET_TOL
     del m
     torch.cuda.empty_cache()
+
+
+F16_NET_TOL = 5e-3  # DRM_PREC_F16 is a reduced-precision mode (one fp16 MFMA per product); its tolerance is its own
+
+
+@pytest.mark.parametrize("name,cfg,kind", [("illnet", ou.ILLNET_CFG, "unet"), ("refnet", ou.REFNET_CFG, "encoder"), ("obsnet", ou.OBSNET_CFG, "unet")])
+def test_plain_f16_mode_full_width_nets(dev, name, cfg, kind):
+    """BASELINE configs[2]'s reduced-precision sampling: same kernels with the lo planes and the two cross products left out.
+    The stated tolerance is 5e-3 rel-L2 against the fp32 reference goldens (measured 3e-4 .. 1.5e-3)."""
+    gd = gold(f"full_{name}_128x128")
+    m = build(cfg, kind, int(gd["seed"]), dev).set_precision("f16")
+    xc, t_emb = full_inputs(2, 128, 128)
+    t = torch.from_numpy(gd["t"]).to(dev)
+    out = m(xc.to(dev), t_emb=t_emb.to(dev)) if name == "illnet" else m(xc.to(dev), t)
+    e = rel_l2(out.cpu(), gd["out"])
+    print(f"plain f16 {name} 2x128x128: rel_l2 {e:.2e}")
+    assert 1e-6 < e < F16_NET_TOL  # reduced precision must be visible (guards against silently running the split path)
+    del m
+    torch.cuda.empty_cache()
