@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="refmaps per GPU (BASELINE config[1]: 32)")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
-    ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim"])
+    ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim", "estimate_chain"])
     ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "f16"],
                     help="conv arithmetic: f16x3 (default) = every fp32 operand split into fp16 hi+lo, 3 MFMAs per product, fp32 "
                          "accumulate: passes the SAME parity tolerances as fp32 (tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32")
@@ -59,6 +59,12 @@ def build_models(workload, dev, precision="fp32"):
     from drmnet_amd import synth
     from drmnet_amd.config import instantiate_from_config, load_config
 
+    if workload == "estimate_chain":  # both models + their dataset transforms (scripts/estimate.py:120-125)
+        drm = build_models("drmnet_step", dev, precision)
+        obs = build_models("obsnet", dev, precision)
+        drm.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/drmnet/eval_drmnet.yaml"))["data"]["params"]["predict"])
+        obs.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["data"]["params"]["predict"])
+        return drm, obs
     if workload in ("drmnet_step", "illnet", "refnet"):
         cfg = load_config(os.path.join(ROOT, "configs/drmnet/eval_drmnet.yaml"))["model"]
         cfg["params"].pop("ckpt_path")
@@ -84,6 +90,35 @@ def make_step(args, model, dev):
     from drmnet_amd import _lib, synth
 
     B, H, W = args.batch, args.height, args.width
+    if args.workload == "estimate_chain":
+        # BASELINE configs[4] / SURVEY 8d config 5: object image + normals + mask -> refmap -> ObsNet DDIM-50 -> DRMNet loop
+        # (150 steps, early exit off so the work is countable) -> Lr0, at the config shape (128x128 refmaps from 256x256 images)
+        import numpy as np
+        from drmnet_amd.estimate import estimate_batch
+
+        drm, obs = model
+        res = drm.ds.size
+        radius = 128
+        lin = np.linspace(-radius + 0.5, radius - 0.5, 2 * radius)
+        xx, yy = np.meshgrid(lin, lin[::-1])
+        zsq = radius ** 2 - (xx ** 2 + yy ** 2)
+        nrm = np.stack([xx, yy, np.sqrt(np.clip(zsq, 0, None))], -1).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+        nrm[zsq < 0] = 0  # unit-sphere normals seen by an orthographic camera (utils/transform.py:147-167)
+        normals = torch.from_numpy(nrm).to(dev).expand(B, -1, -1, -1).contiguous()
+        masks = torch.linalg.norm(normals, dim=-1) > 0.5
+        g = torch.Generator().manual_seed(synth.SEED_INPUT)
+        imgs = (torch.exp(torch.randn((B, 2 * radius, 2 * radius, 3), generator=g) * 0.5 - 2.0)).to(dev)
+        imgs = imgs * (0.2 + normals[..., 2:3].clamp_min(0))  # a shaded sphere with per-pixel texture
+        state = {"n": 0}
+
+        def step():
+            estimate_batch(drm, obs, imgs, normals, masks, early_exit=False, seed=100 + state["n"])
+            state["n"] += 1
+
+        gf = obs.ddim_steps * GFLOP["obsnet"].get((res, res), 0) + drm.max_timesteps * (GFLOP["illnet"].get((res, res), 0) + GFLOP["refnet"].get((res, res), 0))
+        return step, gf, (f"full chain per object image: erosion + refmap_mask_make + ObsNet DDIM-{obs.ddim_steps} + DRMNet loop "
+                          f"({drm.max_timesteps} steps, early exit off) at {res}x{res}; value counts object images")
     x = synth.synth_refmaps(B, H, W, synth.SEED_INPUT).to(dev)
     L = _lib.lib()
     key = (H, W)
@@ -271,9 +306,9 @@ def main():
         total_steps = args.batch * world * args.steps
         value = total_steps / dt
         out = {
-            "metric": "U-Net denoise steps/sec on 3x128x256 refmaps",
+            "metric": "full-chain samples/sec" if args.workload == "estimate_chain" else "U-Net denoise steps/sec on 3x128x256 refmaps",
             "value": round(value, 3),
-            "unit": "denoise steps/sec (samples x steps / s)",
+            "unit": "object images/sec" if args.workload == "estimate_chain" else "denoise steps/sec (samples x steps / s)",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -284,7 +319,7 @@ def main():
             "dtype": {"fp32": "f32", "f16x3": "f32 via split f16x3 MFMA (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)",
                       "f16": "f16 operands, fp32 accumulate (REDUCED PRECISION, ~1e-3 rel-L2: not the headline configuration)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": args.batch, "refmap": f"3x{args.height}x{args.width}",
+            "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": args.batch, "refmap": "3x128x128 (from 256x256 object images)" if args.workload == "estimate_chain" else f"3x{args.height}x{args.width}",
                        "weights": "seeded synthetic (no checkpoint offline)", "parallelism": f"batch-sharded x{world}, no collective",
                        "algorithmic_gflop_per_sample_step": gflop, "achieved_tflops_per_gpu": round(value / world * gflop / 1e3, 2)},
             "roofline": roofline,

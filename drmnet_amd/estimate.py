@@ -54,6 +54,37 @@ def estimate(DRMNet_model, ObsNet_model, input_img: torch.Tensor, input_normal: 
     return Lr0_sample, zK_est
 
 
+@torch.no_grad()
+def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_normals: torch.Tensor, masks: torch.Tensor,
+                   erode_kernel_size: int = 5, *, early_exit: bool = True, seed: Optional[int] = None):
+    """`estimate` for B object images at once (BASELINE configs[4]: the chain batched the way the samplers like it):
+    per-object erosion + refmap gather, then ONE ObsNet DDIM run and ONE DRMNet loop over the whole batch.
+    input_imgs / input_normals [B, H, W, 3], masks [B, H, W] bool  ->  (Lr0 [B, 3, res, res], zK [B, z_dim], K [B])."""
+    refmap_res = DRMNet_model.ds.size
+    refmaps, refmasks = [], []
+    for img, nrm, mask in zip(input_imgs, input_normals, masks):
+        if erode_kernel_size > 0:
+            mask = erode_mask(mask, erode_kernel_size)
+        rm, mk = refmap_mask_make(img[mask], nrm[mask], res=refmap_res, angle_threshold=np.pi / refmap_res / 2)
+        refmaps.append(rm.permute(2, 0, 1))
+        refmasks.append(mk)
+    B = len(refmaps)
+    batch = {"tag": [f"obj{i}" for i in range(B)], "raw_refmap": torch.stack(refmaps), "raw_refmask": torch.stack(refmasks)}
+    c, _, _ = ObsNet_model.get_cond_for_predict(batch)
+    use_ddim = ObsNet_model.ddim_steps is not None
+    extra = {} if seed is None else {"seed": seed}
+    with ObsNet_model.ema_scope("Plotting"):
+        samples, _ = ObsNet_model.sample_log(cond=c, batch_size=B, ddim=use_ddim, ddim_steps=ObsNet_model.ddim_steps, eta=ObsNet_model.ddim_eta, **extra)
+    inpaint = ObsNet_model.ds.rescale(ObsNet_model.decode_first_stage(samples))
+    LrK, _, illnet_c, refnet_c, _ = DRMNet_model.get_input_for_predict({"tag": batch["tag"], "LrK": inpaint})
+    with DRMNet_model.ema_scope():
+        samples, zK_est, K = DRMNet_model.p_sample_loop(LrK, illnet_c, refnet_c, verbose=False, early_exit=early_exit, **extra)
+    Lr0 = DRMNet_model.ds.rescale(DRMNet_model.decode_first_stage(samples)).clip(0)
+    if DRMNet_model.refmap_input_scaler is not None:
+        Lr0 = Lr0 / DRMNet_model.normalizing_scale[:, None, None, None]
+    return Lr0, zK_est, K
+
+
 def main(argv=None):
     from . import file_io
     from .config import instantiate_from_config, load_config
