@@ -1,7 +1,7 @@
 // Split-precision fused GroupNorm+SiLU+conv implicit GEMM, second-generation pipeline (see conv_split.hip for the
 // arithmetic: fp16 hi/lo operands, 3 x v_mfma_f32_32x32x16_f16 per product slab, fp32 accumulate).
 //
-// conv_split.hip measured weight-stream bound: every 768-cycle tap step needed a 16-KB weight tile through
+// The first-generation kernel measured weight-stream bound: every 768-cycle tap step needed a 16-KB weight tile through
 // registers with only one tile in flight, and skipping the weight reloads doubled its speed.  This kernel
 //   * owns 256 output pixels (16x16, or 8x16x2 / 8x8x4 / 4x8x8 / 4x4x16 images) x 128 channels per 512-thread
 //     workgroup (8 wave64, one workgroup per CU): the weight bytes per FLOP are halved;
@@ -10,10 +10,9 @@
 //     (cdna_hip_programming.md "Pipelining across barriers"); the packed weight layout is already the LDS image;
 //   * keeps the activation path of v1: halo tile read once per 32-channel chunk, GroupNorm affine + SiLU + fp16 hi/lo
 //     split applied once in registers, parked in LDS, re-read by the nine taps at shifted offsets;
-//   * is PERSISTENT: a workgroup walks several output tiles; the weight ring and the activation prefetch run straight
-//     across the tile boundary and the epilogue's stores (fire-and-forget) drain under the next tile's MFMAs, so the
-//     HBM write burst of the epilogue is no longer a serial phase of every workgroup (it measured 18 % of a
-//     128->128 @128x256 launch, all CUs bursting at once);
+//   * is PERSISTENT: a workgroup walks several output tiles in an XCD-contiguous range; the weight ring and the activation
+//     prefetch run straight across the tile boundary (no prologue bubble per tile).  The epilogue itself is not hidden:
+//     vmcnt retires stores in order, so the counted waits of the next tile also wait for this tile's stores;
 //   * accumulates the GroupNorm statistics of its OUTPUT in the epilogue (fp32 partials per lane -> fp64 LDS atomics ->
 //     one global fp64 atomic per (image, channel, moment) per tile).
 // All vector-memory operations a wave issues are unconditional (clamped addresses, zero-filled afterwards) so the
