@@ -166,6 +166,33 @@ def make_step(args, model, dev):
     return step, GFLOP["obsnet"].get(key, 0), "ObsNet DDIM step (eta=1)"
 
 
+def parity_check(model, dev, precision):
+    """The networks that were just timed, in the precision they were timed in, against outputs recorded from the REFERENCE
+    (tests/golden/full_*_128x256.npz: same seeded weights and inputs; data files, not the oracle).  Keeps the bench line honest
+    about its arithmetic: the split-precision default must sit at fp32-level error, far inside the 1e-4 contract."""
+    import numpy as np
+    from drmnet_amd import synth
+
+    res = {"tolerance_rel_l2": 1e-4, "cases": {}}
+    try:
+        x = synth.synth_refmaps(1, 128, 256, synth.SEED_INPUT)
+        gen = torch.Generator().manual_seed(synth.SEED_INPUT + 1)
+        xk = x + 0.025 * torch.randn(x.shape, generator=gen)
+        t_emb = torch.randn((1, 128), generator=gen)
+        xc = torch.cat([xk, x], dim=1).contiguous().to(dev)
+        for name, net, kw in (("illnet", model.illnet_model.diffusion_model, "t_emb"), ("refnet", model.refnet_model.diffusion_model, "t")):
+            g = np.load(os.path.join(ROOT, "tests", "golden", f"full_{name}_128x256.npz"))
+            out = net(xc, t_emb=t_emb.to(dev)) if kw == "t_emb" else net(xc, torch.from_numpy(g["t"]).to(dev))
+            ref = torch.from_numpy(g["out"]).double()
+            res["cases"][f"{name} 1x3x128x256 vs reference output"] = float(((out.cpu().double() - ref).norm() / ref.norm()).item())
+        res["max_rel_l2"] = max(res["cases"].values())
+        res["within_tolerance"] = bool(res["max_rel_l2"] < res["tolerance_rel_l2"])
+        res["precision"] = precision
+    except (OSError, KeyError) as e:  # fixtures not shipped with this copy
+        res["error"] = str(e)
+    return res
+
+
 def cpu_baseline(args):
     """Oracle (CPU port of the reference arithmetic) on a bounded sample: batch 1 of the same shape, a few steps."""
     from drmnet_amd import synth
@@ -325,6 +352,8 @@ def main():
             "roofline": roofline,
             "kernel_breakdown": breakdown,
         }
+        if args.workload == "drmnet_step":
+            out["parity_check"] = parity_check(model, dev, args.precision)
         if world == 1 and not args.no_cpu_baseline and args.workload == "drmnet_step":
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
