@@ -114,6 +114,49 @@ __global__ __launch_bounds__(512) void k_rand(float* out, int iters, float seed)
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Operand-toggle experiment: the same 12 products per iteration (4 accumulators x {lo.hi, hi.lo, hi.hi}) on random data,
+// issued in different orders.  ORDER 0: per accumulator (al,bh)(ah,bl)(ah,bh) -- both operands change at almost every MFMA;
+// ORDER 1: B-stationary -- consecutive MFMAs share an operand wherever the dependency structure allows.
+template <int ORDER>
+__global__ __launch_bounds__(512) void k_order(float* out, int iters, float seed) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  f16x8 fr[8];  // 0,1 = ah0,ah1; 2,3 = al0,al1; 4,5 = bh0,bh1; 6,7 = bl0,bl1
+  for (int k = 0; k < 8; ++k)
+    for (int e = 0; e < 8; ++e) {
+      const unsigned hsh = hash32((blockIdx.x * blockDim.x + threadIdx.x) * 64u + k * 8u + e + (unsigned)seed);
+      fr[k][e] = (_Float16)(((int)(hsh & 0xffff) - 32768) * (1.0f / 16384.0f));
+    }
+#define MF(i, ka, kb) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[ka], fr[kb], acc[i], 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+  for (int it = 0; it < iters; ++it) {
+    if (ORDER == 0) {  // acc index = i*2 + c
+      MF(0, 2, 4); MF(0, 0, 6); MF(0, 0, 4);
+      MF(1, 2, 5); MF(1, 0, 7); MF(1, 0, 5);
+      MF(2, 3, 4); MF(2, 1, 6); MF(2, 1, 4);
+      MF(3, 3, 5); MF(3, 1, 7); MF(3, 1, 5);
+    } else if (ORDER == 1) {
+      MF(0, 2, 4); MF(0, 0, 4); MF(2, 1, 4); MF(2, 3, 4);   // bh0 stationary: al0 ah0 ah1 al1
+      MF(3, 3, 5); MF(3, 1, 5); MF(1, 0, 5); MF(1, 2, 5);   // bh1 stationary: al1 ah1 ah0 al0
+      MF(1, 0, 7); MF(3, 1, 7);                             // bl1: ah0 ah1
+      MF(2, 1, 6); MF(0, 0, 6);                             // bl0: ah1 ah0
+    } else {  // what hipcc emits for conv_split2 today: pairs share A
+      MF(0, 2, 4); MF(1, 2, 5); MF(0, 0, 6); MF(1, 0, 7); MF(0, 0, 4); MF(1, 0, 5);
+      MF(2, 3, 4); MF(3, 3, 5); MF(2, 1, 6); MF(3, 1, 7); MF(2, 1, 4); MF(3, 1, 5);
+    }
+    // fresh-looking data every iteration, as in the conv kernel: rotate the fragment registers
+    const f16x8 t = fr[0];
+    fr[0] = fr[1]; fr[1] = t;
+    const f16x8 t2 = fr[4];
+    fr[4] = fr[5]; fr[5] = t2;
+  }
+#undef MF
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // bf16 twin of k_rand<1>: 8 x 8-bit multipliers instead of 11 x 11 -- does the power limit leave it a higher rate?
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(512) void k_rand_bf16(float* out, int iters, float seed) {
@@ -184,6 +227,11 @@ int main(int argc, char** argv) {
   run("f16 random data, 1 w/SIMD", k_rand<0>, 256, 256, 60000, F16, 12, out, secs);
   run("f16 random data, 2 w/SIMD", k_rand<0>, 512, 256, 30000, F16, 12, out, secs);
   run("f16 random rotating, 2 w/SIMD", k_rand<1>, 512, 256, 30000, F16, 12, out, secs);
+  run("order 0 (per-acc)        2 w/SIMD", k_order<0>, 512, 256, 30000, F16, 12, out, secs);
+  run("order 1 (B-stationary)   2 w/SIMD", k_order<1>, 512, 256, 30000, F16, 12, out, secs);
+  run("order 2 (hipcc today)    2 w/SIMD", k_order<2>, 512, 256, 30000, F16, 12, out, secs);
+  run("order 1 (B-stationary)   2 w/SIMD", k_order<1>, 512, 256, 30000, F16, 12, out, secs);
+  run("order 0 (per-acc)        2 w/SIMD", k_order<0>, 512, 256, 30000, F16, 12, out, secs);
   run("bf16 random rotating, 2 w/SIMD", k_rand_bf16, 512, 256, 30000, F16, 12, out, secs);
   run("f32 32x32x2, 1 wave/SIMD", k_f32<4>, 256, 256, 100000, F32, 4, out, secs);
   run("f32 32x32x2, 2 waves/SIMD", k_f32<4>, 512, 256, 50000, F32, 4, out, secs);
