@@ -65,6 +65,7 @@ struct ConvArgs {
   float* out = nullptr;             // NHWC [N,H,W,Cout], or NCHW [N,cout_valid,H,W] if out_nchw
   int out_nchw = 0, cout_valid = 0;
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
+  int ksplit = 1;                      // split-K factor (conv_split_ksplit); > 1: partial results are added into `out`
   int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 1 = plain fp16 operands
   unsigned long long* trace = nullptr;  // experiment build only: per-wave phase cycle counters
   int dbg = 0;                         // experiment switches (DRM_DBG env): 1 skip B reloads, 2 skip A reloads, 4 skip MFMA, 8 skip barriers
@@ -74,6 +75,7 @@ struct ConvArgs {
 int launch_conv(const ConvArgs& a, hipStream_t s);
 // split-precision (fp16 hi/lo x 3 MFMA, fp32-accurate) variant; a.w = pre-split weights (conv_split.hip)
 int launch_conv_split(const ConvArgs& a, hipStream_t s);
+int conv_split_ksplit(const ConvArgs& a);  // split-K factor the split kernels want for this launch (1 = none)
 bool conv_split_fuses_stats();  // true when the active split kernel accumulates ConvArgs::stat_out in its epilogue
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);
 int launch_pack_conv_weight_split(const float* w, float* packed, float* scales, unsigned* scratch, int Cout, int Cin, int taps, int CoutP,

@@ -17,6 +17,7 @@
 //     one global fp64 atomic per (image, channel, moment) per tile).
 // All vector-memory operations a wave issues are unconditional (clamped addresses, zero-filled afterwards) so the
 // vmcnt bookkeeping below is exact and identical for every wave.
+#include <algorithm>
 #include <utility>
 #include <vector>
 #include <cstdio>
@@ -204,7 +205,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   TilePos cur = decode(x_start + k_tile);
 
   const int Ctot = a.C0 + a.C1;
-  const int nchunks = Ctot / C::KC;
+  // split-K (deep, small maps: too few output tiles to fill the chip, long K): blockIdx.y owns a contiguous range of the
+  // 32-channel chunks and ADDS its partial result into the pre-zeroed output; bias / emb / residual come from split 0
+  const int nch_all = Ctot / C::KC;
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  const int split = blockIdx.y;
+  const int chunk0 = split * nch_all / ks;
+  const int nchunks = (split + 1) * nch_all / ks - chunk0;  // chunks of THIS workgroup (indices below are local)
   const int NGT = nchunks * C::NG;  // weight groups (pipeline steps) per tile
   const bool has_gn = a.gn_scale != nullptr;
 
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   unsigned avalid = 0;
 
   auto load_A_piece = [&](const TilePos& tp, int chunk, int piece) {
-    const int c = chunk * C::KC;
+    const int c = (chunk0 + chunk) * C::KC;
     const float* src;
     int Cs, coff, up;
     if (c < a.C0) {
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     const int chunk = g_in_tile / C::NG, g = g_in_tile - chunk * C::NG;
     const int u = k / C::B_PER, j = k % C::B_PER;
     const int tap = g * TPS + u;
-    const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nchunks + chunk) * 8) * a.Cout + co0;
+    const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nch_all + chunk0 + chunk) * 8) * a.Cout + co0;
     const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
     if (base >= C::B_DMA_F4) return;           // (single-product mode on narrow tiles: the upper waves have nothing to fetch)
     const int idx = base + lane;
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
     for (int u = 0; u < TPS; ++u) {
       const int tap = g * TPS + u;
-      const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nchunks + chunk) * 8) * a.Cout + co0;
+      const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nch_all + chunk0 + chunk) * 8) * a.Cout + co0;
 #pragma unroll
       for (int j = 0; j < C::B_PER; ++j) {
         const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
@@ -625,11 +632,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       for (int c = 0; c < NT; ++c) {
         const int col = (wn * NT + c) * 32 + r;
         const int co = cur.co0 + col;
-        const float bias = a.bias ? a.bias[co] : 0.f;
+        const bool first = split == 0;
+        const float bias = (a.bias && first) ? a.bias[co] : 0.f;
         float rv[16], ev[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) ev[g] = a.emb ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
-        if (a.res) {
+        for (int g = 0; g < 4; ++g) ev[g] = (a.emb && first) ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
+        if (a.res && first && !(ks > 1 && a.res == a.out)) {  // split-K on an in-place residual: `out` already holds it
 #pragma unroll
           for (int e = 0; e < 16; ++e) rv[e] = a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co];
         } else {
@@ -649,6 +657,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
                 const size_t hw = (size_t)a.H * a.W;
                 a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v;
               }
+            } else if (ks > 1) {
+              unsafeAtomicAdd(&a.out[(pixb[g] + (e & 3)) * a.Cout + co], v);  // global_atomic_add_f32, no return
             } else {
               a.out[(pixb[g] + (e & 3)) * a.Cout + co] = v;
             }
@@ -727,7 +737,12 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
   const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds_bytes), 8 / C::NW));
   long long grid = 256ll * per_cu;
   const int ngt = ((a.C0 + a.C1) / C::KC) * C::NG;  // weight groups per tile
-  if (no_persist || tiles < grid || ngt < R - 1 || (TAPS == 1 && ngt < 2)) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  DRM_REQUIRE(ks == 1 || (TAPS == 9 && !a.out_nchw && !a.stat_out && ((a.C0 + a.C1) / C::KC) / ks >= 1), "split-K launch contract");
+  if (no_persist || tiles < grid || ngt < R - 1 || (TAPS == 1 && ngt < 2) || ks > 1) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
+  // partial results are ADDED into the output: it starts from zero -- or, for an in-place residual (res == out, the ResBlock
+  // skip-conv case), from the residual itself
+  if (ks > 1 && a.res != a.out) DRM_HIP_CHECK(hipMemsetAsync(a.out, 0, (size_t)a.N * a.H * a.W * a.Cout * sizeof(float), s));
   {
     const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
     const double px = (double)a.N * a.H * a.W;
@@ -745,7 +760,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
       DRM_HIP_CHECK(hipMemsetAsync(trace_buf, 0, trace_n * 8, s));
       at.trace = trace_buf;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHR), lds_bytes, s, at);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes, s, at);
     if (at.trace) {
       std::vector<unsigned long long> h(trace_n);
       DRM_HIP_CHECK(hipStreamSynchronize(s));
@@ -767,7 +782,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
                 lo[hf][4] / nlo[hf], lo[hf][5] / nlo[hf], lo[hf][6] / nlo[hf]);
     }
 #else
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHR), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes, s, a);
 #endif
   }
   DRM_HIP_CHECK(hipGetLastError());
@@ -818,6 +833,23 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
   if (a.H % 4 == 0 && a.W % 4 == 0) return dispatch_s2_bn<TAPS, 4, 4, 4, 4, TERMS>(a, s);
   set_error("conv: feature map " + std::to_string(a.H) + "x" + std::to_string(a.W) + " is not a multiple of 4x4");
   return DRM_ERR_INVALID;
+}
+
+// Split-K factor for a launch (1 = none).  Mirrors dispatch_s2_bn: only the 128-row x 32-channel fallback tiles qualify, when
+// their grid leaves most of the 256 CUs idle and the reduction is long; the caller zero-fills nothing (the launcher does) but
+// must not ask for fused output statistics (partial sums have no statistics) -- engine.hip:run_conv checks this first.
+int conv_split_ksplit(const ConvArgs& a) {
+  static const int off = getenv("DRM_NO_SPLITK") ? 1 : 0;
+  if (off || a.taps != 9 || a.out_nchw) return 1;
+  const long long rows = (long long)a.N * a.H * a.W;
+  auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
+  if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) return 1;
+  if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) return 1;
+  if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return 1;
+  const long long tiles = wgs(128, 32);
+  const int nch = (a.C0 + a.C1) / 32;
+  const long long ks = std::min<long long>(std::min<long long>(8, nch / 4), 640 / std::max<long long>(tiles, 1));
+  return (int)std::max<long long>(ks, 1);
 }
 
 int launch_conv_split2(const ConvArgs& a, hipStream_t s) {

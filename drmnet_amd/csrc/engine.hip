@@ -245,7 +245,8 @@ int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_
   if (c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0) {
     a.w_inv_scale = Wb + scale_off + 1;
     a.terms = c.terms();
-    if (stats_for && !a.out_nchw && conv_split_fuses_stats()) {
+    a.ksplit = conv_split_ksplit(a);  // deep levels: split the reduction over workgroups (no fused statistics then)
+    if (stats_for && !a.out_nchw && conv_split_fuses_stats() && a.ksplit == 1) {
       if (!stats_for->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(stats_for->mom, 0, (size_t)c.N * stats_for->C * sizeof(double2), c.s));
       a.stat_out = stats_for->mom;
       stats_for->mom_valid = true;
