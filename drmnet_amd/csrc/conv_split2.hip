@@ -104,6 +104,7 @@ struct S2Cfg {
   static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
   static_assert(B_DMA_F4 % 64 == 0 && B_PER >= 1, "whole 1-KiB LDS-DMA instructions; a wave issues B_PER of them or none");
   static_assert(TERMS == 3 || TERMS == 1, "3 = fp16 hi/lo split (fp32 accuracy), 1 = plain fp16 operands");
+  static_assert(TERMS == 1 || B_DMA_F4 % NTHR == 0, "split mode: every wave owns the same number of distinct 1-KiB pieces");
   static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
   static_assert(R >= 2, "ring needs >= 2 slots");
 };
@@ -315,8 +316,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     const int u = k / C::B_PER, j = k % C::B_PER;
     const int tap = g * TPS + u;
     const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nch_all + chunk0 + chunk) * 8) * a.Cout + co0;
-    const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
-    if (base >= C::B_DMA_F4) return;           // (single-product mode on narrow tiles: the upper waves have nothing to fetch)
+    // wave-uniform float4 index inside the tile.  Single-product mode on narrow tiles has fewer 1-KiB pieces than waves: the
+    // upper waves re-fetch a piece (same bytes to the same LDS address) so that EVERY wave issues the same number of
+    // vector-memory operations -- the counted waits rely on that.
+    const int base = (wave * 64 + C::NTHR * j) % C::B_DMA_F4;
     const int idx = base + lane;
     const int seg = idx / C::BN, co = idx % C::BN;
     glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
@@ -330,8 +333,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nch_all + chunk0 + chunk) * 8) * a.Cout + co0;
 #pragma unroll
       for (int j = 0; j < C::B_PER; ++j) {
-        const int base = wave * 64 + C::NTHR * j;  // wave-uniform float4 index inside the tile
-        if (base >= C::B_DMA_F4) continue;
+        const int base = (wave * 64 + C::NTHR * j) % C::B_DMA_F4;  // (see issue_G1)
         const int idx = base + lane;
         const int seg = idx / C::BN, co = idx % C::BN;
         glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
