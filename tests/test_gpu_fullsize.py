@@ -64,3 +64,41 @@ def test_refnet_batch32_and_row_gather(dev):
     assert rel_l2(out[0].cpu(), gd["out"][0]) < NET_TOL and rel_l2(out[31].cpu(), gd["out"][0]) < NET_TOL
     del m
     torch.cuda.empty_cache()
+
+
+def test_full_width_drmnet_loop_device_vs_host_driven(dev):
+    """Full-width RefNet + IllNet through both loop implementations at the config shape (128x128): the device-side loop
+    behind drm_drmnet_sample and the host-driven one over drm_drmnet_step (return_intermediates) must agree row by row (the
+    per-sample early-exit bookkeeping itself is pinned by the tiny-net reference traces in test_gpu_samplers.py)."""
+    import os
+
+    from drmnet_amd import synth
+    from drmnet_amd.config import instantiate_from_config, load_config
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(root, "configs/drmnet/eval_drmnet.yaml"))["model"]
+    cfg["params"].pop("ckpt_path")
+    cfg["params"].update(use_ema=False, max_timesteps=4, epsilon=0.9, gamma=0.9)
+    m = instantiate_from_config(cfg)
+    synth.load_synth(m.illnet_model.diffusion_model, synth.SEED_ILLNET)
+    synth.load_synth(m.refnet_model.diffusion_model, synth.SEED_REFNET)
+    m.illnet_model.z_emb_layer.load_state_dict(synth.synth_state_dict(
+        [(k, tuple(v.shape)) for k, v in m.illnet_model.z_emb_layer.state_dict().items()], synth.SEED_ZEMB))
+    sd = m.refnet_model.diffusion_model.state_dict()
+    sd["out.3.weight"] = sd["out.3.weight"] * 8.0
+    sd["out.3.bias"] = torch.tensor([0.95, 0.9, 0.97, 0.92, 0.05, 0.9])
+    m.refnet_model.diffusion_model.load_state_dict(sd)
+    m = m.to(dev).set_precision("f16x3")
+    B = 6
+    LrK = synth.synth_refmaps(B, 128, 128, 77).to(dev)
+    g = torch.Generator().manual_seed(9)
+    n0 = torch.randn(LrK.shape, generator=g).to(dev)
+    sn = torch.randn((4,) + tuple(LrK.shape), generator=g).to(dev)
+    Lr0, zK, K = m.p_sample_loop(LrK, [LrK], [LrK], verbose=False, noise0=n0, step_noise=sn)
+    Lr0h, zKh, Kh, inter = m.p_sample_loop(LrK, [LrK], [LrK], return_intermediates=True, verbose=False, log_every_k=1, noise0=n0, step_noise=sn)
+    print("full-width loop K =", K.tolist(), "rel", rel_l2(Lr0.cpu(), Lr0h.cpu()))
+    assert K.tolist() == Kh.tolist() and torch.isfinite(Lr0).all()
+    assert rel_l2(Lr0.cpu(), Lr0h.cpu()) < 1e-5
+    assert torch.allclose(torch.nan_to_num(zK), torch.nan_to_num(zKh), atol=1e-5)
+    del m
+    torch.cuda.empty_cache()
