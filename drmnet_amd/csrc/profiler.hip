@@ -17,7 +17,7 @@ struct Rec {
   int tag[5];
 };
 int g_tag[5] = {0, 0, 0, 0, 0};
-bool g_on = false;
+int g_on = 0;  // 0 off, 1 every kernel family, 2 the dominant family (fused 3x3 convs) only: least perturbation of a timed region
 std::vector<Rec> g_pool;   // event pairs, reused after each collect
 size_t g_used = 0;
 double g_ms[PROF_KINDS], g_fl[PROF_KINDS], g_by[PROF_KINDS];
@@ -27,11 +27,11 @@ int64_t g_n[PROF_KINDS];
 void prof_tag(int n, int h, int w, int cin, int cout) {
   g_tag[0] = n; g_tag[1] = h; g_tag[2] = w; g_tag[3] = cin; g_tag[4] = cout;
 }
-void prof_enable(int on) { g_on = on != 0; }
-bool prof_enabled() { return g_on; }
+void prof_enable(int on) { g_on = on < 0 ? 0 : on; }
+bool prof_enabled() { return g_on != 0; }
 
 ProfScope::ProfScope(int k, double flops, double bytes, hipStream_t st) : kind(k), slot(-1), s(st) {
-  if (!g_on) return;
+  if (!g_on || (g_on == 2 && k != PROF_CONV3)) return;
   if (g_used == g_pool.size()) {
     Rec r{};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
