@@ -52,6 +52,7 @@ def parse():
                          "accumulate: passes the SAME parity tolerances as fp32 (tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the batch-1 parity forward passes (keeps a rocprofv3 trace of this command to the timed workload's launches)")
     return ap.parse_args()
 
 
@@ -336,7 +337,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
                     pmc = json.load(f)["kernels"]
-                key = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3>"
+                key = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3>"
                 if split and key in pmc and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256):
                     roofline["traffic"] = pmc[key]["hbm_bytes_per_launch_corrected"]
                     roofline["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch of " + key + ")"
@@ -367,7 +368,7 @@ def main():
             "kernel_breakdown": breakdown,
             "kernel_breakdown_note": "conv3x3 row and the roofline object: HIP events inside the timed region; other rows: a second, untimed pass of the same steps with every kernel family instrumented",
         }
-        if args.workload == "drmnet_step":
+        if args.workload == "drmnet_step" and not args.no_parity_check:
             out["parity_check"] = parity_check(model, dev, args.precision)
         if world == 1 and not args.no_cpu_baseline and args.workload == "drmnet_step":
             out["cpu_baseline"] = cpu_baseline(args)
