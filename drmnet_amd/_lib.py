@@ -13,8 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DRM_LIB=exp selects the experiment build of tools/build_exp.sh (kernel-internals timing switches; never the default)
-LIB_PATH = os.path.join(_HERE, "csrc", "libdrmnet_hip_exp.so" if os.environ.get("DRM_LIB") == "exp" else "libdrmnet_hip.so")
+LIB_PATH = os.path.join(_HERE, "csrc", "libdrmnet_hip.so")
+ABI_VERSION = 2
 MAX_LEVELS = 8
 
 # every symbol include/drmnet_hip.h declares (tests check the .so exports all of them)
@@ -27,6 +27,8 @@ SYMBOLS = [
     "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddpm_sample", "drm_randn",
     "drm_profile_enable", "drm_profile_reset", "drm_profile_collect", "drm_unet_set_precision", "drm_set_op_precision",
     "drm_refmap_workspace_bytes", "drm_refmap_mask_make", "drm_erode_mask",
+    "drm_unet_load_params_set", "drm_unet_use_set",
+    "drm_map_chain", "drm_masked_log_range", "drm_luminance_scale", "drm_mirmap2envmap", "drm_hdr2ldr",
 ]
 
 
@@ -67,6 +69,8 @@ def lib() -> C.CDLL:
     L.drm_unet_param_count.argtypes = [vp]
     L.drm_unet_param_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.drm_unet_load_params.argtypes = [vp, C.POINTER(vp), i32, vp]
+    L.drm_unet_load_params_set.argtypes = [vp, i32, C.POINTER(vp), i32, vp]
+    L.drm_unet_use_set.argtypes = [vp, i32]
     L.drm_unet_workspace_bytes.argtypes = [vp, i32, i32, i32]
     L.drm_unet_workspace_bytes.restype = C.c_size_t
     L.drm_unet_forward.argtypes = [vp, fp, i32, fp, i32, vp, fp, i64p, fp, fp, i32, i32, i32, vp, C.c_size_t, vp]
@@ -98,8 +102,13 @@ def lib() -> C.CDLL:
     L.drm_profile_enable.restype = None
     L.drm_profile_reset.restype = None
     L.drm_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.drm_abi_version() != 1:
-        raise RuntimeError("libdrmnet_hip.so ABI version mismatch")
+    L.drm_map_chain.argtypes = [fp, fp, C.c_int64, i32, C.POINTER(C.c_int32), C.POINTER(C.c_float), i32, fp, fp, fp, vp]
+    L.drm_masked_log_range.argtypes = [fp, fp, i32, i32, i32, fp, fp, vp]
+    L.drm_luminance_scale.argtypes = [fp, i32, i32, C.c_float, fp, vp]
+    L.drm_mirmap2envmap.argtypes = [fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.drm_hdr2ldr.argtypes = [fp, u8p, i32, C.c_float, C.c_float, fp, vp]
+    if L.drm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libdrmnet_hip.so ABI version {L.drm_abi_version()} != {ABI_VERSION}: rebuild with `python -m drmnet_amd.build`")
     _lib = L
     return L
 

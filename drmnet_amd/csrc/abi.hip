@@ -126,7 +126,22 @@ int drm_unet_param_info(const drm_unet* net, int index, char* name, int name_cap
 int drm_unet_load_params(drm_unet* net, const float* const* ptrs, int count, void* stream) {
   return guarded([&]() -> int {
     DRM_REQUIRE(net && ptrs, "null argument");
-    return net->net.load(ptrs, count, static_cast<hipStream_t>(stream));
+    return net->net.load(ptrs, count, static_cast<hipStream_t>(stream), net->net.active);
+  });
+}
+
+int drm_unet_load_params_set(drm_unet* net, int set, const float* const* ptrs, int count, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && ptrs, "null argument");
+    return net->net.load(ptrs, count, static_cast<hipStream_t>(stream), set);
+  });
+}
+
+int drm_unet_use_set(drm_unet* net, int set) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && set >= 0 && set < UNet::NSETS, "weight set index");
+    net->net.active = set;
+    return DRM_OK;
   });
 }
 
@@ -423,6 +438,32 @@ int drm_erode_mask(const uint8_t* mask, int H, int W, int kernel_size, uint8_t* 
     DRM_REQUIRE(mask && out, "drm_erode_mask: null pointer");
     return launch_erode_mask(mask, H, W, kernel_size, out, static_cast<hipStream_t>(stream));
   });
+}
+
+// ------------------------------------------------------------------------------------------------ boundary maps (transform.hip)
+
+int drm_map_chain(const float* x, float* out, int64_t per_image, int B, const int32_t* ops, const float* args, int n_ops, const float* lo,
+                  const float* hi, const float* scale, void* stream) {
+  return guarded([&]() -> int { return launch_map_chain(x, out, per_image, B, ops, args, n_ops, lo, hi, scale, static_cast<hipStream_t>(stream)); });
+}
+
+int drm_masked_log_range(const float* x, const float* mask, int B, int C, int HW, float* lo, float* hi, void* stream) {
+  return guarded([&]() -> int { return launch_masked_log_range(x, mask, B, C, HW, lo, hi, static_cast<hipStream_t>(stream)); });
+}
+
+int drm_luminance_scale(const float* x, int B, int HW, float scaler, float* scale, void* stream) {
+  return guarded([&]() -> int { return launch_luminance_scale(x, B, HW, scaler, scale, static_cast<hipStream_t>(stream)); });
+}
+
+int drm_mirmap2envmap(const float* mirmap, const float* basis, float* out, int B, int C, int H, int W, int OH, int OW, int log_scale_interpolation,
+                      int channels_last, void* stream) {
+  return guarded([&]() -> int {
+    return launch_mirmap2envmap(mirmap, basis, out, B, C, H, W, OH, OW, log_scale_interpolation, channels_last, static_cast<hipStream_t>(stream));
+  });
+}
+
+int drm_hdr2ldr(const float* x, const uint8_t* mask, int HW, float alpha, float gamma, float* out, void* stream) {
+  return guarded([&]() -> int { return launch_hdr2ldr(x, mask, HW, alpha, gamma, out, static_cast<hipStream_t>(stream)); });
 }
 
 }  // extern "C"

@@ -41,6 +41,18 @@ const char* last_error();
     if (_s != DRM_OK) return _s; \
   } while (0)
 
+// The kernels are written for one device shape: gfx950 / MI355X = 256 CUs in 8 XCDs (workgroups b and b + 8 share an XCD and
+// its L2), 160 KiB of LDS per CU.  device_info() reads the CURRENT device's properties once per device ordinal and returns
+// null -- with the error text set -- when they do not match, so a launch on anything else fails loudly instead of running a
+// mis-sized persistent grid.  Thread-safe; one process may drive several GPUs (one stream / handle set per device).
+struct DeviceInfo {
+  int ordinal = 0;
+  int cus = 0;          // 256
+  int xcds = 0;         // 8
+  size_t lds_per_cu = 0;  // 163840
+};
+const DeviceInfo* device_info();
+
 // ---------------------------------------------------------------------------------------------
 // Activation layout: NHWC fp32 ("pixels x channels", channels contiguous) everywhere inside the
 // network; NCHW only at the boundary (reference tensors are NCHW).
@@ -67,8 +79,6 @@ struct ConvArgs {
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
   int ksplit = 1;                      // split-K factor (conv_split_ksplit); > 1: partial results are added into `out`
   int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 1 = plain fp16 operands
-  unsigned long long* trace = nullptr;  // experiment build only: per-wave phase cycle counters
-  int dbg = 0;                         // experiment switches (DRM_DBG env): 1 skip B reloads, 2 skip A reloads, 4 skip MFMA, 8 skip barriers
   double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)
   const float* w_inv_scale = nullptr;  // split-precision path: device scalar 2^-k undoing the weight pre-scaling
 };
@@ -101,6 +111,15 @@ int launch_refmap_mask_make(const float* colors, const float* normals, long long
 int launch_erode_mask(const unsigned char* mask, int H, int W, int k, unsigned char* out, hipStream_t s);
 // terms: 0 = fp32 MFMA, 3 = fp16 hi/lo split, 1 = plain fp16 operands
 int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms = 0);
+
+// boundary maps and the envmap warp (transform.hip)
+int launch_map_chain(const float* x, float* out, long long per_image, int B, const int32_t* ops, const float* args, int n_ops, const float* lo,
+                     const float* hi, const float* scale, hipStream_t s);
+int launch_masked_log_range(const float* x, const float* mask, int B, int C, int HW, float* lo, float* hi, hipStream_t s);
+int launch_luminance_scale(const float* x, int B, int HW, float scaler, float* scale, hipStream_t s);
+int launch_mirmap2envmap(const float* mir, const float* basis, float* out, int B, int C, int H, int W, int OH, int OW, int log_interp, int nhwc,
+                         hipStream_t s);
+int launch_hdr2ldr(const float* x, const unsigned char* mask, int HW, float alpha, float gamma, float* out, hipStream_t s);
 
 // misc kernels (misc.hip)
 int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s);

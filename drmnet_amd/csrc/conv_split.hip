@@ -14,41 +14,23 @@
 //     halves stay in the fp16 normal range; the epilogue multiplies by the inverse scale (exact).
 // LDS images: A = [hi|lo][slab s][lane-half h][pixel][8 halfs], B = [hi|lo][s][h][cout][8 halfs]; one ds_read_b128 per
 // operand fragment (lane (r,h) of slab s needs channels 16s + 8h .. +7 of row/col r).
-// This file holds the dispatcher and the weight pre-split / packing kernels; the conv kernels are conv_split2.hip (default)
-// and conv_split3.hip (producer / consumer experiment).  The first-generation kernel (weights through registers, one tile
-// in flight: 254 steps/s) was removed once conv_split2 replaced it.
+// This file holds the dispatcher and the weight pre-split / packing kernels; the conv kernel is conv_split2.hip.
 #include "common.h"
 #include "profiler.h"
 
 namespace drm {
 
 int launch_conv_split2(const ConvArgs& a, hipStream_t s);
-int launch_conv_split3(const ConvArgs& a, hipStream_t s, bool& handled);
 
 // the split kernels accumulate ConvArgs::stat_out (GroupNorm statistics of their output) in the epilogue
 bool conv_split_fuses_stats() { return true; }
 
-int launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
-  ConvArgs a = a_in;
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("DRM_DBG");
-      dbg = e ? atoi(e) : 0;
-    }
-    a.dbg = dbg;
-  }
+int launch_conv_split(const ConvArgs& a, hipStream_t s) {
   const int Ctot = a.C0 + a.C1;
   DRM_REQUIRE(a.taps == 9 || a.taps == 1, "conv taps must be 9 or 1");
   DRM_REQUIRE(a.Cout % 32 == 0 && Ctot % 32 == 0 && a.C0 % 32 == 0, "split conv needs channels % 32 == 0");
   DRM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, "conv shape");
   DRM_REQUIRE(!a.up0 || (a.H % 2 == 0 && a.W % 2 == 0), "upsampled source needs even output size");
-  static const int use_s3 = getenv("DRM_S3") ? atoi(getenv("DRM_S3")) : 0;
-  if (use_s3 && a.taps == 9 && a.terms == 3) {  // producer / consumer waves (conv_split3.hip), opt-in experiment
-    bool handled = false;
-    const int rc = launch_conv_split3(a, s, handled);
-    if (handled) return rc;
-  }
   return launch_conv_split2(a, s);  // LDS-DMA weight ring, 256-pixel tiles (conv_split2.hip)
 }
 

@@ -18,29 +18,13 @@
 // All vector-memory operations a wave issues are unconditional (clamped addresses, zero-filled afterwards) so the
 // vmcnt bookkeeping below is exact and identical for every wave.
 #include <algorithm>
+#include <atomic>
 #include <utility>
 #include <vector>
 #include <cstdio>
 
 #include "common.h"
 #include "profiler.h"
-
-// Experiment build (-DDRM_S2_EXP, tools/build_exp.sh): DRM_DBG bits switch parts of the 3x3 main loop off so their
-// cost can be read off a timing difference.  1 no weight DMA, 2 no activation staging, 4 no LDS reads + MFMAs,
-// 8 MFMAs from stale registers (no LDS fragment reads), 16 no barriers.  The product build has none of these branches.
-#ifdef DRM_S2_EXP
-#define S2X(bit) (a.dbg & (bit))
-#else
-#define S2X(bit) 0
-#endif
-// Phase timers of the experiment build: s_memtime deltas accumulated per wave (0 weight DMA issue, 1 activation load issue,
-// 2 LDS fragment reads + MFMA issue, 3 counted vmcnt wait, 4 barrier, 5 activation staging, 6 epilogue, 7 statistics fold).
-#ifdef DRM_S2_EXP
-#define TSTAMP(k) do { const unsigned long long t_now_ = clock64(); tacc[k] += t_now_ - t_prev; t_prev = t_now_; } while (0)
-#else
-#define TSTAMP(k) do { } while (0)
-#endif
-#define S2_BARRIER() do { if (!S2X(16)) __builtin_amdgcn_s_barrier(); } while (0)
 
 namespace drm {
 
@@ -64,10 +48,7 @@ struct S2Cfg {
   static constexpr bool SUB48 = (TW % 8 == 0) && (TH % 4 == 0);
   static constexpr int WTP_TRY = (TAPS == 9 && TW == 16) ? 24 : WT;
   static constexpr int RING_ST_F4 = R * TPS * 8 * (WN * NT * 32) + TN * (WN * NT * 32);
-  // 3x3 with one tap per step and a >= 4-slot ring: the halo tile is double-buffered when two copies fit, so the
-  // GroupNorm/SiLU/split staging of the next chunk runs under the MFMAs of this one instead of between two barriers.
-  static constexpr bool DB = (TAPS == 9) && (TPS == 1) && (R >= 4) && (2 * 8 * TN * HT * WT + RING_ST_F4) * 16 <= 160 * 1024;
-  static constexpr int A_COPIES = (TAPS == 1 || DB) ? 2 : 1;
+  static constexpr int A_COPIES = (TAPS == 1) ? 2 : 1;  // 1x1: a new activation tile every step, double-buffered
   static constexpr bool PAD_FITS = (A_COPIES * 8 * TN * HT * WTP_TRY + RING_ST_F4) * 16 <= 160 * 1024;
   static constexpr int WTP = PAD_FITS ? WTP_TRY : WT;  // stored row stride (pixels)
   static constexpr int HPIP = HT * WTP;                // stored pixels per image
@@ -198,11 +179,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   };
   int k_tile = jx;  // index inside this XCD's range
   if (k_tile >= x_count) return;
-#ifdef DRM_S2_EXP
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long t_begin = clock64();
-  unsigned long long t_prev = t_begin;
-#endif
   TilePos cur = decode(x_start + k_tile);
 
   const int Ctot = a.C0 + a.C1;
@@ -402,25 +378,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   //   (3) MFMAs of the TPS taps of the group,
   //   (4) counted wait: everything up to the next group landed; allowed in flight = the R-2 younger groups
   //       (+ the activation loads while they are younger than the next group), then ONE barrier per TPS taps.
-  //   Double-buffered 3x3 (C::DB): the request goes out at group 2, is complete (in-order retirement) by the end of group
-  //   2+R-1, and is staged into the OTHER tile buffer at the start of group 2+R; no extra barrier.
-  constexpr int A_G = C::DB ? 2 : ((C::NG >= 3) ? C::NG - 2 : 0);
-  constexpr int STORE_G = A_G + R;
-  constexpr int STORE_STEPS = C::DB ? C::NG - STORE_G : 1;  // staging slots are dealt to the last steps of the chunk
-  static_assert(!C::DB || STORE_STEPS >= 1, "double-buffered staging must fit inside the chunk");
+  constexpr int A_G = (C::NG >= 3) ? C::NG - 2 : 0;
   // The two waves that share a SIMD (w and w + NW/2 of an 8-wave workgroup) run the two halves of every step in opposite
   // order: one issues DMA / loads / staging VALU work while the other owns the MFMA pipe, then they swap.  Measured with
   // the phase timers of the experiment build: with every wave doing the same phase at the same time the MFMA pipe sat
   // idle 55 % of the main loop (17 % in DMA issue alone: the CU's texture-address path serialises the 1-KiB DMAs).
-  const bool y_first = (C::NW == 8) && (wave >= C::NW / 2) && !(a.dbg & 128);
+  const bool y_first = (C::NW == 8) && (wave >= C::NW / 2);
   constexpr int BASE = C::G_PER * (R - 2);
   int step = 0;  // steps executed so far (== gseq - (R-1))
-  int abuf = 0;  // activation tile buffer being read (double-buffered 3x3)
-#ifdef DRM_S2_EXP
-  F4H8b ah[MT], al[MT], bh[NT], bl[NT];  // bit 8: MFMAs run on whatever these hold
-  for (int i = 0; i < MT; ++i) ah[i].f4 = al[i].f4 = As[tid];
-  for (int c = 0; c < NT; ++c) bh[c].f4 = bl[c].f4 = As[tid + 64];
-#endif
   while (true) {
     const bool has_next = k_tile + J < x_count;
     const TilePos nxt = has_next ? decode(x_start + k_tile + J) : cur;
@@ -429,20 +394,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int seg = s2 * 2 + h;
-#ifndef DRM_S2_EXP
         F4H8b ah[MT], al[MT], bh[NT], bl[NT];
-#endif
-        if (!S2X(8)) {
 #pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            ah[i].f4 = Ab[seg * C::HP + a_base[i] + tapoff];
-            if (TERMS == 3) al[i].f4 = Ab[(4 + seg) * C::HP + a_base[i] + tapoff];
-          }
+        for (int i = 0; i < MT; ++i) {
+          ah[i].f4 = Ab[seg * C::HP + a_base[i] + tapoff];
+          if (TERMS == 3) al[i].f4 = Ab[(4 + seg) * C::HP + a_base[i] + tapoff];
+        }
 #pragma unroll
-          for (int c = 0; c < NT; ++c) {
-            bh[c].f4 = Bc[seg * C::BN + b_base[c]];
-            if (TERMS == 3) bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
-          }
+        for (int c = 0; c < NT; ++c) {
+          bh[c].f4 = Bc[seg * C::BN + b_base[c]];
+          if (TERMS == 3) bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -473,7 +434,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         if (gi >= NGT) gi %= NGT;
         co0 = nxt.co0;
       }
-      if (!S2X(1)) issue_G(gseq, gi, co0);
+      issue_G(gseq, gi, co0);
       ++gseq;
     };
     if constexpr (TAPS == 1) {
@@ -506,24 +467,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         __builtin_amdgcn_s_barrier();
       }
     } else {
-    const int nch_run = (a.dbg & 64) ? 1 : nchunks;  // experiment switch: run a single K chunk
+    const int nch_run = nchunks;
     for (int chunk = 0; chunk < nch_run; ++chunk) {
       const bool more = chunk + 1 < nch_run;
       const bool a_next = more || has_next;  // activations to stage at the end of this chunk
       static_for(std::make_integer_sequence<int, C::NG>{}, [&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr bool last_g = (g == C::NG - 1);
-        // side work of the step: staging slots of the double-buffered tile, weight DMA R-1 steps ahead, activation request
-        auto side = [&]() {
-          if constexpr (C::DB && g >= STORE_G) {
-            if (a_next && !S2X(2)) {
-              if (g == STORE_G) tie_A();  // complete since the counted wait that ended step STORE_G-1
-#pragma unroll
-              for (int j = 0; j < C::A_SLOTS; ++j)
-                if (STORE_G + (j % STORE_STEPS) == g) store_A_slot(As + (abuf ^ 1) * C::A1_F4, j);
-            }
-          }
-        };
         // group R-1 steps ahead: inside this tile, else the matching group of the next tile (else a harmless re-read)
         int d_gi = chunk * C::NG + g + (R - 1);
         int d_co0 = cur.co0;
@@ -533,7 +483,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           d_co0 = nxt.co0;
         }
         const int d_seq = gseq++;
-        const bool a_req = (g == A_G) && a_next && !S2X(2);
+        const bool a_req = (g == A_G) && a_next;
         // Hook points of a step: 2 per tap (one per 16-channel slab).  The DMA instructions go to the first hook points,
         // the activation request (in pieces) to the later ones, so the request stays younger than the whole group.
         constexpr int HPN = 2 * TPS;
@@ -542,14 +492,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         constexpr int A_PIECES = C::A_SLOTS + 1;
         auto compute = [&]() {
           const float4* Bg = Bs + (step % R) * C::G_F4;
-          const float4* Ac = As + (C::DB ? abuf * C::A1_F4 : 0);
-          if (!S2X(4))
+          const float4* Ac = As;
 #pragma unroll
           for (int u = 0; u < TPS; ++u) {
             const int tap = g * TPS + u;
             mma_tap(Ac, Bg + u * C::B_F4, (tap / 3) * C::WTP + (tap % 3), [&](int s2) {
               const int hp = u * 2 + s2;
-              if (hp < DMA_HP && !S2X(1)) {
+              if (hp < DMA_HP) {
 #pragma unroll
                 for (int k = hp * C::G_PER / DMA_HP; k < (hp + 1) * C::G_PER / DMA_HP; ++k) issue_G1(d_seq, d_gi, d_co0, k);
               }
@@ -564,46 +513,27 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             });
           }
         };
-        if (!y_first) side();
-        TSTAMP(0);
         compute();
-        TSTAMP(2);
-        if (y_first) side();
-        TSTAMP(0);
         ++step;
         constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
-        if constexpr (C::DB) {
-          if (a_younger && a_next) wait_vmcnt<BASE + C::A_CNT>();
-          else wait_vmcnt<BASE>();
-          if (g >= STORE_G) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staged slots visible before the tile is read
-          TSTAMP(3);
-          S2_BARRIER();
-          TSTAMP(4);
-          if (last_g && a_next) abuf ^= 1;
-        } else if (last_g) {
-          if (a_next && !S2X(2)) {
-            S2_BARRIER();  // every wave finished reading the old activation tile
-            TSTAMP(4);
+        if (last_g) {
+          if (a_next) {
+            __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
             wait_vmcnt<C::G_PER * (C::NG - 1 - A_G)>();  // the request of group A_G; younger: the weight groups issued after it
             store_A(As);
-            TSTAMP(5);
             wait_vmcnt<BASE>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            TSTAMP(3);
-            S2_BARRIER();
-            TSTAMP(4);
+            __builtin_amdgcn_s_barrier();
           } else {
             wait_vmcnt<BASE>();
-            S2_BARRIER();
+            __builtin_amdgcn_s_barrier();
           }
         } else {
           // the activation loads were issued right after the group of step (A_G)+R-1: they are younger than the next
           // group while g - A_G <= R-2
           if (a_younger && a_next) wait_vmcnt<BASE + C::A_CNT>();
           else wait_vmcnt<BASE>();
-          TSTAMP(3);
-          S2_BARRIER();
-          TSTAMP(4);
+          __builtin_amdgcn_s_barrier();
         }
       });
     }
@@ -614,7 +544,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     // the four k rows are four consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per
     // (i, g).  Loads are issued unconditionally on clamped addresses (batched ahead of the math); stores are predicated
     // and fire-and-forget: they drain while the next tile's main loop runs.
-    if (!(a.dbg & 32))  // experiment switch: skip the epilogue
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       size_t pixb[4];
@@ -690,7 +619,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         }
       }
     }
-    TSTAMP(6);
     if (st) {
       // fold of this tile's statistics: LDS -> one global fp64 atomic per (image, channel, moment); re-zero for the next tile
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -704,19 +632,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    TSTAMP(7);
     if (!has_next) break;
     k_tile += J;
     cur = nxt;
   }
-#ifdef DRM_S2_EXP
-  if (a.trace && lane == 0) {
-    unsigned long long* tr = a.trace + ((size_t)blockIdx.x * C::NW + wave) * 10;
-    for (int k = 0; k < 8; ++k) tr[k] = tacc[k];
-    tr[8] = clock64() - t_begin;
-    tr[9] = 1;
-  }
-#endif
   wait_vmcnt<0>();  // drain the tail DMAs before the workgroup's LDS can be re-assigned
 }
 
@@ -726,22 +645,25 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
   auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
   const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
   static_assert(C::LDS_F4 * 16 <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set && lds_bytes > 48 * 1024) {
+  const DeviceInfo* di = device_info();  // fails loudly on anything that is not an MI355X-shaped gfx950 (256 CUs, 160 KiB LDS)
+  if (!di) return DRM_ERR_STATE;
+  // the opt-in LDS size is a per-device function attribute: one bit per device ordinal, set idempotently (a racing second
+  // thread at worst repeats the call), so the entry points stay re-entrant across streams, threads and devices
+  static std::atomic<uint64_t> attr_mask{0};
+  if (lds_bytes > 48 * 1024 && !(attr_mask.load(std::memory_order_acquire) >> di->ordinal & 1)) {
     DRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
+    attr_mask.fetch_or(uint64_t(1) << di->ordinal, std::memory_order_release);
   }
   const int groups = (a.N + C::TN - 1) / C::TN;
   const long long tiles = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
   DRM_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv grid size");
   // persistent grid: as many workgroups as stay resident (256 CUs x workgroups per CU by LDS), a multiple of 8 (XCDs)
-  static const int no_persist = getenv("DRM_S2_NOPERSIST") ? 1 : 0;
-  const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds_bytes), 8 / C::NW));
-  long long grid = 256ll * per_cu;
+  const int per_cu = std::max(1, std::min((int)(di->lds_per_cu / lds_bytes), 8 / C::NW));
+  long long grid = (long long)di->cus * per_cu;
   const int ngt = ((a.C0 + a.C1) / C::KC) * C::NG;  // weight groups per tile
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   DRM_REQUIRE(ks == 1 || (TAPS == 9 && !a.out_nchw && !a.stat_out && ((a.C0 + a.C1) / C::KC) / ks >= 1), "split-K launch contract");
-  if (no_persist || tiles < grid || ngt < R - 1 || (TAPS == 1 && ngt < 2) || ks > 1) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
+  if (tiles < grid || ngt < R - 1 || (TAPS == 1 && ngt < 2) || ks > 1) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
   // partial results are ADDED into the output: it starts from zero -- or, for an in-place residual (res == out, the ResBlock
   // skip-conv case), from the residual itself
   if (ks > 1 && a.res != a.out) DRM_HIP_CHECK(hipMemsetAsync(a.out, 0, (size_t)a.N * a.H * a.W * a.Cout * sizeof(float), s));
@@ -752,40 +674,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     prof_tag(a.N, a.H, a.W, a.C0 + a.C1, a.Cout);
     ProfScope ps(TAPS == 9 ? PROF_CONV3 : PROF_CONV1, 2.0 * px * TAPS * cin * cout,
                  4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
-#ifdef DRM_S2_EXP
-    static unsigned long long* trace_buf = nullptr;
-    static const int want_trace = getenv("DRM_S2_TRACE") ? 1 : 0;
-    ConvArgs at = a;
-    const size_t trace_n = (size_t)grid * C::NW * 10;
-    if (want_trace && TAPS == 9) {
-      if (!trace_buf) DRM_HIP_CHECK(hipMalloc(&trace_buf, (size_t)1 << 26));
-      DRM_HIP_CHECK(hipMemsetAsync(trace_buf, 0, trace_n * 8, s));
-      at.trace = trace_buf;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes, s, at);
-    if (at.trace) {
-      std::vector<unsigned long long> h(trace_n);
-      DRM_HIP_CHECK(hipStreamSynchronize(s));
-      DRM_HIP_CHECK(hipMemcpy(h.data(), trace_buf, trace_n * 8, hipMemcpyDeviceToHost));
-      double acc[9] = {0}, lo[2][9] = {{0}};
-      size_t nw = 0, nlo[2] = {0, 0};
-      for (size_t w = 0; w < (size_t)grid * C::NW; ++w) {
-        if (!h[w * 10 + 9]) continue;
-        ++nw;
-        const int half = (int)(w % C::NW) >= C::NW / 2;
-        ++nlo[half];
-        for (int k = 0; k < 9; ++k) { acc[k] += (double)h[w * 10 + k]; lo[half][k] += (double)h[w * 10 + k]; }
-      }
-      fprintf(stderr, "s2 trace <%d,%d,%d,%d,%d,%d,%d,R%d,TPS%d> C%d->%d %dx%d grid %lld: mean cycles/wave total %.0f | dma %.0f loadA %.0f mfma %.0f vmwait %.0f barrier %.0f stage %.0f epi %.0f fold %.0f\n",
-              TAPS, TH, TW, WM, WN, MT, NT, R, TPS, a.C0 + a.C1, a.Cout, a.H, a.W, grid, acc[8] / nw, acc[0] / nw, acc[1] / nw, acc[2] / nw,
-              acc[3] / nw, acc[4] / nw, acc[5] / nw, acc[6] / nw, acc[7] / nw);
-      for (int hf = 0; hf < 2; ++hf)
-        fprintf(stderr, "   waves %s: mfma %.0f vmwait %.0f barrier %.0f stage %.0f epi %.0f\n", hf ? "4-7" : "0-3", lo[hf][2] / nlo[hf], lo[hf][3] / nlo[hf],
-                lo[hf][4] / nlo[hf], lo[hf][5] / nlo[hf], lo[hf][6] / nlo[hf]);
-    }
-#else
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes, s, a);
-#endif
   }
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
@@ -803,22 +692,11 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   constexpr int TPS = (TAPS == 9) ? 3 : 1;
   constexpr int RG = (TAPS == 9) ? 2 : 4;
   constexpr bool big_ok = (TAPS == 1) || (TH >= 8);
-  static const int no_db = getenv("DRM_S2_DB") ? 0 : 1;  // A/B switch: DRM_S2_DB=1 selects the double-buffered halo tile variants
   if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) {
-    if constexpr (TAPS == 9 && big_ok && TERMS == 3) {
-      if constexpr (S2Cfg<TAPS, TH, TW, 4, 2, 2, 2, 4, 1>::DB) {
-        if (!no_db) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, 4, 1, TERMS>(a, s);
-      }
-    }
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
   }
   if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) {
-    if constexpr (TAPS == 9 && big_ok && TERMS == 3) {
-      if constexpr (S2Cfg<TAPS, TH, TW, 4, 2, 2, 1, 4, 1>::DB) {
-        if (!no_db) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, 4, 1, TERMS>(a, s);
-      }
-    }
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
   }
@@ -841,8 +719,7 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
 // their grid leaves most of the 256 CUs idle and the reduction is long; the caller zero-fills nothing (the launcher does) but
 // must not ask for fused output statistics (partial sums have no statistics) -- engine.hip:run_conv checks this first.
 int conv_split_ksplit(const ConvArgs& a) {
-  static const int off = getenv("DRM_NO_SPLITK") ? 1 : 0;
-  if (off || a.taps != 9 || a.out_nchw) return 1;
+  if (a.taps != 9 || a.out_nchw) return 1;
   const long long rows = (long long)a.N * a.H * a.W;
   auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
   if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) return 1;

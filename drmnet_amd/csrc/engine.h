@@ -106,13 +106,18 @@ class UNet {
   // packed-buffer offsets
   size_t te0_w = 0, te0_b = 0, te2_w = 0, te2_b = 0, stem_w = 0, stem_b = 0, embcat_w = 0, embcat_b = 0, on_w = 0, on_b = 0, oc_w = 0, oc_b = 0, oc_s = 0, scratch_off = 0;
   size_t wbuf_floats = 0;
-  float* wbuf = nullptr;  // device
-  bool loaded = false;
-  int precision = PREC_FP32;         // arithmetic of the conv kernels: PREC_FP32 (v_mfma_f32_32x32x2_f32) or PREC_F16X3 (split fp16)
-  int loaded_precision = -1;
+  // Packed weight images.  A network keeps up to DRM_WEIGHT_SETS of them side by side (set 0 = the live parameters, set 1 = the
+  // EMA shadow the reference swaps in for sampling, ema.py:46-76): each is packed / pre-split ONCE and selected per forward, so
+  // entering and leaving ema_scope costs no re-upload.
+  static constexpr int NSETS = DRM_WEIGHT_SETS;
+  float* wsets[NSETS] = {nullptr, nullptr};  // device
+  bool loaded[NSETS] = {false, false};
+  int loaded_precision[NSETS] = {-1, -1};
+  int active = 0;                    // the set forward() reads
+  int precision = PREC_FP32;         // arithmetic of the conv kernels: PREC_FP32 (v_mfma_f32_32x32x2_f32), PREC_F16X3 (split fp16) or PREC_F16
 
   int build(const drm_unet_desc& d);
-  int load(const float* const* ptrs, int count, hipStream_t s);
+  int load(const float* const* ptrs, int count, hipStream_t s, int set);
   std::map<std::tuple<int, int, int>, size_t> stats_pool_cache;  // (N, H, W) -> bytes of the statistics pool
   int forward(const float* x, int Cx, const float* cond, int Cc, const int32_t* rows, const float* t_emb, const int64_t* t, const float* tf,
               float* out, int N, int H, int W, Arena& ar, hipStream_t s);

@@ -10,7 +10,9 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <deque>
+#include <mutex>
 
 namespace drm {
 
@@ -18,10 +20,51 @@ static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 const char* last_error() { return g_err.c_str(); }
 
+const DeviceInfo* device_info() {
+  constexpr int MAX_DEV = 64;
+  static DeviceInfo info[MAX_DEV];
+  static std::atomic<int> state[MAX_DEV];  // 0 unknown, 1 valid, 2 rejected (zero-initialised)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+    set_error("device_info: no current HIP device");
+    return nullptr;
+  }
+  int st = state[dev].load(std::memory_order_acquire);
+  if (st == 0) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    st = state[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+      hipDeviceProp_t p;
+      if (hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        set_error("device_info: hipGetDeviceProperties failed");
+        return nullptr;
+      }
+      DeviceInfo d;
+      d.ordinal = dev;
+      d.cus = p.multiProcessorCount;
+      d.lds_per_cu = p.maxSharedMemoryPerMultiProcessor;
+      const std::string arch = p.gcnArchName;
+      // XCD count is not a device property: it is 8 on the one part this library targets (gfx950 with 256 CUs)
+      d.xcds = (arch.rfind("gfx950", 0) == 0 && d.cus == 256) ? 8 : 0;
+      info[dev] = d;
+      st = (d.xcds == 8 && d.lds_per_cu >= 160 * 1024) ? 1 : 2;
+      state[dev].store(st, std::memory_order_release);
+    }
+  }
+  if (st != 1) {
+    set_error("unsupported device " + std::to_string(dev) + ": libdrmnet_hip is built for MI355X (gfx950, 256 CUs in 8 XCDs, 160 KiB LDS per CU); found " +
+              std::to_string(info[dev].cus) + " CUs, " + std::to_string(info[dev].lds_per_cu) + " B LDS per CU");
+    return nullptr;
+  }
+  return &info[dev];
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 UNet::~UNet() {
-  if (wbuf) (void)hipFree(wbuf);
+  for (float* w : wsets)
+    if (w) (void)hipFree(w);
 }
 
 size_t UNet::add_copy(const std::string& name, std::vector<int64_t> shape, size_t padded_count) {
@@ -198,9 +241,12 @@ int UNet::build(const drm_unet_desc& d) {
   return DRM_OK;
 }
 
-int UNet::load(const float* const* ptrs, int count, hipStream_t s) {
+int UNet::load(const float* const* ptrs, int count, hipStream_t s, int set) {
+  DRM_REQUIRE(set >= 0 && set < NSETS, "weight set index");
   DRM_REQUIRE(count == (int)params.size(), "parameter count mismatch: got " + std::to_string(count) + ", expected " + std::to_string(params.size()));
-  if (!wbuf) DRM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wbuf), wbuf_floats * sizeof(float)));
+  if (!wsets[set]) DRM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wsets[set]), wbuf_floats * sizeof(float)));
+  float* wbuf = wsets[set];
+  loaded[set] = false;
   DRM_HIP_CHECK(hipMemsetAsync(wbuf, 0, wbuf_floats * sizeof(float), s));
   for (size_t i = 0; i < params.size(); ++i) {
     const ParamSlot& p = params[i];
@@ -214,8 +260,8 @@ int UNet::load(const float* const* ptrs, int count, hipStream_t s) {
       DRM_TRY(launch_pack_conv_weight(ptrs[i], wbuf + p.dst, p.cout, p.cin, p.taps, p.coutp, p.cinp, s));
     }
   }
-  loaded = true;
-  loaded_precision = precision;
+  loaded[set] = true;
+  loaded_precision[set] = precision;
   return DRM_OK;
 }
 
@@ -341,7 +387,7 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
 
 int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32_t* rows, const float* t_emb, const int64_t* t,
                   const float* tf, float* out, int N, int H, int W, Arena& ar, hipStream_t s) {
-  DRM_REQUIRE(ar.dry || loaded, "drm_unet_forward before drm_unet_load_params");
+  DRM_REQUIRE(ar.dry || loaded[active], "drm_unet_forward before drm_unet_load_params (weight set " + std::to_string(active) + ")");
   DRM_REQUIRE(N > 0, "batch size");
   DRM_REQUIRE(Cx + Cc == desc.in_channels, "x/cond channels must sum to in_channels");
   const int down = 1 << (desc.n_levels - 1);
@@ -352,9 +398,9 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
     if (desc.kind == 0) DRM_REQUIRE(n_t == 1, "timesteps and t_emb cannot be specified at the same time");
     else DRM_REQUIRE(n_t == 1 && t_emb == nullptr, "EncoderUNetModel takes timesteps");
   }
-  DRM_REQUIRE(ar.dry || loaded_precision == precision, "precision changed after drm_unet_load_params: reload the parameters");
+  DRM_REQUIRE(ar.dry || loaded_precision[active] == precision, "precision changed after drm_unet_load_params: reload the parameters");
   Ctx c{&ar, s, N, precision};
-  const float* Wb = wbuf;
+  const float* Wb = wsets[active];
   const int mc = desc.model_channels;
 
   // statistics pool: sized by a dry pass (cached per shape), zeroed once

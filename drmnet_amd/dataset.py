@@ -1,95 +1,109 @@
-"""HDR <-> network-space maps used either side of the samplers.
+"""``BaseDataset`` -- the HDR <-> network-space maps either side of both samplers, on the HIP map kernels.
 
-Mirror of ``dataset.basedataset.BaseDataset.transform / rescale`` (reference dataset/basedataset.py:29-112):
-a ``transform_func`` string of ``_``-separated names applied right-to-left (f_g = f(g(x))) and inverted
-left-to-right.  Elementwise torch ops on whatever device the tensor lives on -- host glue, not the hot path.
+Operator surface of ``dataset.basedataset.BaseDataset`` (reference dataset/basedataset.py:10-112): ``size``, ``transform(x,
+dynamic_normalize=False, mask=None)``, ``rescale(x)`` and the ``transform_func`` string -- ``_``-separated map names read like
+function composition (``f_g`` = f(g(x))), so ``transform`` runs them right to left and ``rescale`` runs the inverses left to
+right.  Here the string is compiled once into two op lists for ``drm_map_chain`` (csrc/transform.hip): a whole chain is ONE pass
+over the tensor; the only data-dependent piece, the per-image masked (log10 min, log10 max) of ``normalizedLogarithmic``
+(:63-69), is one reduction launch in front of the pass that needs it, and -- like the reference (:69) -- is remembered on the
+dataset object for the matching ``rescale``.  GPU tensors only: there is no torch fallback.
 """
 from __future__ import annotations
 
+import math
+from typing import List, Optional, Tuple
+
 import torch
+
+from . import ops
+
+# map name -> (forward step, inverse steps); None = identity.  "@" marks the clamp_before_exp argument, "b" the lowerbound value.
+_TABLE = {
+    "log": (("log_p1", 0.0), (("exp_m1", "@"),)),
+    "log10": (("log10", 0.0), (("exp10", "@"),)),
+    "0p1tom1p1": (("unit_to_signed", 0.0), (("signed_to_unit", 0.0),)),
+    "normalizedLogarithmic": (("norm_log", 0.0), (("denorm_log", 0.0), ("exp10", "@"))),
+}
 
 
 class BaseDataset(torch.utils.data.Dataset):
     def __init__(self, size: int, transform_func: str = "log", clamp_before_exp: float = 0.0):
         self.size = size
         self.transform_func_str = transform_func
-        self.clamp_before_exp = 10 if isinstance(clamp_before_exp, bool) and not clamp_before_exp else clamp_before_exp
+        # basedataset.py:25: a literal False selects 10; any other value is used as given, and a falsy one means "no clamp" (:88,:94)
+        self.clamp_before_exp = 10 if clamp_before_exp is False else clamp_before_exp
+        self.Logarithmic_params = None  # [log10min, log10max], each [B, 1, 1, 1] (or [1, 1, 1] for a 3-D input), set by transform(dynamic_normalize=True)
         names = transform_func.split("_")
-        self.transform_funcs = [self.get_tranfrom_func(n) for n in names[::-1]]
-        self.rescale_funcs = [self.get_rescale_func(n) for n in names]
+        self._forward: List[Tuple[str, float]] = []
+        self._resize_modes: List[str] = []
+        for name in reversed(names):
+            step = self._compile(name, inverse=False)
+            self._forward.extend(step)
+        self._inverse: List[Tuple[str, float]] = []
+        for name in names:
+            self._inverse.extend(self._compile(name, inverse=True))
+
+    # ------------------------------------------------------------------ compilation of the name string
+    def _compile(self, name: str, inverse: bool) -> List[Tuple[str, float]]:
+        if not name or "_" in name:
+            raise NotImplementedError(name)
+        cap = float(self.clamp_before_exp) if self.clamp_before_exp else math.inf
+        if name.startswith("resize"):
+            if not inverse:
+                self._resize_modes.append("bilinear" if name == "resize" else name[len("resize"):].replace("-", "_").lower())
+            return []  # shape change, not an elementwise map: handled in transform(); rescale leaves the size alone (:86-87)
+        if name.startswith("lowerbound"):
+            return [] if inverse else [("lowerbound", float(name[len("lowerbound"):]))]
+        if name not in _TABLE:
+            raise NotImplementedError(name)
+        fwd, inv = _TABLE[name]
+        return [(n, cap if a == "@" else a) for n, a in inv] if inverse else [fwd]
+
+    # kept for callers that ask for a single named map (same (sic) spelling as the reference, :42 / :82)
+    def get_tranfrom_func(self, func_name: str):
+        steps = self._compile(func_name, inverse=False)
+        return lambda x, **kw: self._run(x, steps, **kw)
+
+    def get_rescale_func(self, func_name: str):
+        steps = self._compile(func_name, inverse=True)
+        return lambda x, **kw: self._run(x, steps)
+
+    # ------------------------------------------------------------------ execution
+    def _run(self, x: torch.Tensor, steps, dynamic_normalize: bool = False, mask: Optional[torch.Tensor] = None):
+        if not x.is_cuda:
+            raise RuntimeError("BaseDataset maps run on the GPU (drmnet_amd has no CPU path); got a CPU tensor")
+        x = x.float().contiguous()
+        names = [n for n, _ in steps]
+        lo = hi = None
+        if "norm_log" in names and dynamic_normalize:
+            if mask is None:
+                raise AssertionError("dynamic_normalize needs a mask")
+            cut = names.index("norm_log")
+            if cut:  # the statistics are taken on the output of the maps in front (e.g. lowerbound1e-6)
+                x = ops.map_chain(x, steps[:cut])
+                steps = steps[cut:]
+            lo, hi = ops.masked_log_range(x, mask)
+            keep = (-1,) + (1,) * 3 if x.ndim >= 4 else (1, 1, 1)
+            self.Logarithmic_params = [lo.view(keep), hi.view(keep)]
+        if any(n in ("norm_log", "denorm_log") for n, _ in steps):
+            if self.Logarithmic_params is None:
+                raise RuntimeError("normalizedLogarithmic: call transform(..., dynamic_normalize=True, mask=...) first")
+            lo, hi = (p.to(x.device) for p in self.Logarithmic_params)
+            if lo.ndim != x.ndim:
+                raise AssertionError(f"{x.ndim}, {lo.ndim}, {hi.ndim}")
+        return ops.map_chain(x, steps, lo=lo, hi=hi) if steps else x
 
     def transform(self, x: torch.Tensor, dynamic_normalize: bool = False, mask: torch.Tensor = None):
         assert x.size(-1) >= self.size
-        for func in self.transform_funcs:
-            x = func(x, dynamic_normalize=dynamic_normalize, mask=mask)
-        return x
+        y = self._run(x, self._forward, dynamic_normalize=dynamic_normalize, mask=mask)
+        for mode in self._resize_modes:
+            if y.shape[-1] != self.size or y.shape[-2] != self.size:
+                # the shipped path never gets here (refmaps are produced at `size`); an actual resize is torch glue, not a kernel
+                aa = mode in ("bilinear", "bicubic")
+                flat = y.reshape(-1, 1, *y.shape[-2:])
+                flat = torch.nn.functional.interpolate(flat, size=(self.size, self.size), mode=mode, antialias=aa, align_corners=False if aa else None)
+                y = flat.reshape(*y.shape[:-2], self.size, self.size)
+        return y
 
     def rescale(self, x: torch.Tensor):
-        for func in self.rescale_funcs:
-            x = func(x)
-        return x
-
-    def get_tranfrom_func(self, func_name: str):  # (sic) reference spelling kept
-        assert "_" not in func_name
-        if func_name.startswith("resize"):
-            def resize(x, **kwargs):
-                if x.shape[-1] == self.size and x.shape[-2] == self.size:
-                    return x
-                mode = "bilinear" if len(func_name) == 6 else func_name[6:].replace("-", "_").lower()
-                lead = x.shape[:-2]
-                y = torch.nn.functional.interpolate(x.reshape(-1, 1, *x.shape[-2:]), size=(self.size, self.size), mode=mode,
-                                                    antialias=mode in ("bilinear", "bicubic"),
-                                                    align_corners=False if mode in ("bilinear", "bicubic") else None)
-                return y.reshape(*lead, self.size, self.size)
-            return resize
-        elif func_name == "log":
-            return lambda x, **kwargs: torch.log10(x + 1e-1) + 1
-        elif func_name == "log10":
-            return lambda x, **kwargs: torch.log10(x)
-        elif func_name.startswith("lowerbound"):
-            bottom = float(func_name[10:])
-            return lambda x, **kwargs: torch.clip(x, bottom)
-        elif func_name == "0p1tom1p1":
-            return lambda x, **kwargs: x * 2 - 1
-        elif func_name == "normalizedLogarithmic":
-            def func(x: torch.Tensor, mask: torch.Tensor, dynamic_normalize: bool, **kwargs):
-                if dynamic_normalize:
-                    assert mask is not None
-                    linearmax = (x * mask).amax(dim=(-1, -2, -3), keepdim=True)
-                    log10max = torch.log10(linearmax)
-                    log10min = torch.log10((x * mask + (1 - mask.float()) * linearmax).amin(dim=(-1, -2, -3), keepdim=True))
-                    self.Logarithmic_params = [log10min, log10max]  # state kept on the dataset object (basedataset.py:69)
-                log10min, log10max = self.Logarithmic_params
-                assert x.ndim == log10min.ndim == log10max.ndim, f"{x.ndim}, {log10min.ndim}, {log10max.ndim}"
-                log10min, log10max = log10min.to(x.device), log10max.to(x.device)
-                return (torch.log10(x) - log10min) / (log10max - log10min)
-            return func
-        raise NotImplementedError(func_name)
-
-    def get_rescale_func(self, func_name: str):
-        do_nothing = lambda x, **kwargs: x
-        assert "_" not in func_name
-        if func_name.startswith("resize"):
-            return do_nothing
-        elif func_name == "log":
-            if self.clamp_before_exp:
-                return lambda x, **kwargs: torch.pow(10, torch.clamp(x - 1, max=self.clamp_before_exp)) - 1e-1
-            return lambda x, **kwargs: torch.pow(10, x - 1) - 1e-1
-        elif func_name == "log10":
-            if self.clamp_before_exp:
-                return lambda x, **kwargs: torch.pow(10, torch.clamp(x, max=self.clamp_before_exp))
-            return lambda x, **kwargs: torch.pow(10, x)
-        elif func_name.startswith("lowerbound"):
-            return do_nothing
-        elif func_name == "0p1tom1p1":
-            return lambda x, **kwargs: (x + 1) / 2
-        elif func_name == "normalizedLogarithmic":
-            log10 = self.get_rescale_func("log10")
-
-            def func(x: torch.Tensor, **kwargs):
-                log10min, log10max = self.Logarithmic_params
-                log10min, log10max = log10min.to(x.device), log10max.to(x.device)
-                assert x.ndim == log10min.ndim == log10max.ndim
-                return log10(x * (log10max - log10min) + log10min, **kwargs)
-            return func
-        raise NotImplementedError(func_name)
+        return self._run(x, self._inverse)

@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from contextlib import contextmanager
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -23,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib
 from .config import instantiate_from_config
-from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma, ZEmbDiffusionWrapper
+from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma, ZEmbDiffusionWrapper, ema_weights, load_checkpoint
 
 
 class DRMNet(nn.Module):
@@ -124,8 +123,8 @@ class DRMNet(nn.Module):
         self.delta = delta
         self.refmap_input_scaler = refmap_input_scaler
         self.eval()
-        self._sampler = None
-        self._sampler_sig = None
+        self._samplers = {}  # weight set ("live" / "ema") -> (drm_drmnet handle, signature it was built from)
+        self._weight_set = "live"
         self._ws = _lib.Workspace()
 
     # ------------------------------------------------------------------ plumbing kept from the reference
@@ -141,39 +140,15 @@ class DRMNet(nn.Module):
             basis_r0 = torch.ones(3, self.image_size, self.image_size)
         self.register_buffer("basis_r0", basis_r0.float(), persistent=False)
 
-    @contextmanager
     def ema_scope(self, context=None):
-        if self.use_ema:
-            self.illnet_model_ema.store(self.illnet_model.parameters())
-            self.refnet_model_ema.store(self.refnet_model.parameters())
-            self.illnet_model_ema.copy_to(self.illnet_model)
-            self.refnet_model_ema.copy_to(self.refnet_model)
-            if context is not None:
-                print(f"{context}: Switched to EMA weights")
-        try:
-            yield None
-        finally:
-            if self.use_ema:
-                self.illnet_model_ema.restore(self.illnet_model.parameters())
-                self.refnet_model_ema.restore(self.refnet_model.parameters())
-                if context is not None:
-                    print(f"{context}: Restored training weights")
+        """models/drmnet.py:242-258 -- ``with model.ema_scope(): ...`` samples with the EMA weights of both networks (and of the
+        z-embedding MLP, which lives in illnet_model); see wrappers.ema_weights."""
+        pairs = [(self.illnet_model, self.illnet_model_ema), (self.refnet_model, self.refnet_model_ema)] if self.use_ema else []
+        return ema_weights(self, pairs, context)
 
     def init_from_ckpt(self, path, ignore_keys=list(), only_model=False, verbose=True):
-        sd = torch.load(path, map_location="cpu")
-        if "state_dict" in list(sd.keys()):
-            sd = sd["state_dict"]
-        for k in list(sd.keys()):
-            for ik in ignore_keys:
-                if k.startswith(ik):
-                    print("Deleting key {} from state_dict.".format(k))
-                    del sd[k]
-        missing, unexpected = self.load_state_dict(sd, strict=False) if not only_model else self.illnet_model.load_state_dict(sd, strict=False)
-        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
-        if len(missing) > 0 and verbose:
-            print(f"Missing Keys: {missing}")
-        if len(unexpected) > 0 and verbose:
-            print(f"Unexpected Keys: {unexpected}")
+        """models/drmnet.py:260-277 (``only_model`` loads into illnet_model alone, as there)."""
+        load_checkpoint(self, path, ignore_keys, into=self.illnet_model if only_model else None, verbose=verbose)
 
     @torch.no_grad()
     def encode_first_stage(self, x):
@@ -200,28 +175,32 @@ class DRMNet(nn.Module):
         return model(input_refmap, k, rows=rows, **cond)
 
     def get_schedule(self, zK, z0=None, reversed_k=None, normalized_k=None, return_zkm1=False, power_precision=torch.double):
-        """drmnet.py:458-501 (tiny [n, z_dim] host-side math; the sampler kernels restate the reversed_k branch)."""
-        z0 = self.z0 if z0 is None else z0.to(zK.device)
-        Delta_K = zK - z0
-        log_gamma = math.log(self.gamma)
-        distance = torch.linalg.norm(Delta_K, dim=-1)
-        K = (torch.log(self.epsilon / distance) / math.log(self.gamma)).int() + 2
-        assert (normalized_k is None) ^ (reversed_k is None), "normalized_k and reversed_k are exclusive"
-        if normalized_k is not None:
+        """models/drmnet.py:458-501.  The BRDF code decays geometrically from zK towards the mirror code z0: after ``r`` reverse
+        steps the offset is gamma^r (zK - z0), with gamma^r evaluated as exp(r ln gamma) in ``power_precision`` (fp64) and cast to
+        fp32 before the multiply.  K = int(log_gamma(epsilon / |zK - z0|)) + 2 is the step count at which the offset falls below
+        epsilon.  Exactly one of ``reversed_k`` (steps done) / ``normalized_k`` (fraction of K) selects the point.
+        Returns (K, k, zk[, zk one step later]).  Tiny [n, z_dim] host-side math; the sampler kernels restate the reversed_k branch."""
+        if (normalized_k is None) == (reversed_k is None):
+            raise AssertionError("normalized_k and reversed_k are exclusive")
+        anchor = self.z0 if z0 is None else z0.to(zK.device)
+        offset = zK - anchor
+        ln_gamma = math.log(self.gamma)
+        K = (torch.log(self.epsilon / torch.linalg.norm(offset, dim=-1)) / ln_gamma).int() + 2
+        if normalized_k is None:
+            k = K - reversed_k - 1
+            steps = torch.tensor([reversed_k], device=zK.device) if isinstance(reversed_k, int) else reversed_k
+        else:
             K = K.clip(min=1).int()
             k = (normalized_k * K).int()
-            reversed_k = K - k - 1
-        else:
-            k = K - reversed_k - 1
-            if isinstance(reversed_k, int):
-                reversed_k = torch.tensor([reversed_k], device=zK.device)
-        reversed_k = reversed_k.to(power_precision)
-        Delta_k = torch.exp(reversed_k.unsqueeze(-1) * log_gamma).float() * Delta_K
-        zk = Delta_k + z0
+            steps = K - k - 1
+        steps = steps.to(power_precision)
+
+        def code_after(r):
+            return torch.exp(r.unsqueeze(-1) * ln_gamma).float() * offset + anchor
+
         if return_zkm1:
-            zkm1 = torch.exp((reversed_k + 1).unsqueeze(-1) * math.log(self.gamma)).float() * Delta_K + z0
-            return K, k, zk, zkm1
-        return K, k, zk
+            return K, k, code_after(steps), code_after(steps + 1)
+        return K, k, code_after(steps)
 
     def get_brdf_out(self, brdf_model_out, reversed_k=None):
         zK = brdf_model_out
@@ -259,16 +238,23 @@ class DRMNet(nn.Module):
 
     # ------------------------------------------------------------------ the device sampler
     def _engine(self):
+        """The device sampler handle for the weight set that is live right now ("live" parameters, or the EMA shadow inside
+        ``ema_scope``): one handle per set, rebuilt only when something it was built from changes."""
+        which = getattr(self, "_weight_set", "live")
         ill, ref = self.illnet_model.diffusion_model, self.refnet_model.diffusion_model
         hi, hr = ill.engine_handle(), ref.engine_handle()
-        zp = [p.detach() for p in self.illnet_model.z_emb_params()]
+        if which == "ema":
+            zp = self.illnet_model_ema.shadow_for(self.illnet_model.z_emb_param_names())
+        else:
+            zp = [p.detach() for p in self.illnet_model.z_emb_params()]
         for p in zp:
             _lib.require_gpu_tensor(p, "z_emb_layer parameter")
-        sig = (hi.value, hr.value, ill.precision, ref.precision, tuple((p.data_ptr(), p._version) for p in zp), float(self.gamma), float(self.epsilon), float(self.delta),
-               int(self.max_timesteps), tuple(self._z0.tolist()))
-        if self._sampler is not None and sig == self._sampler_sig:
-            return self._sampler
-        self._free_sampler()
+        sig = (hi.value, hr.value, ill.precision, ref.precision, tuple((p.data_ptr(), p._version) for p in zp), float(self.gamma), float(self.epsilon),
+               float(self.delta), int(self.max_timesteps), tuple(self._z0.tolist()))
+        cached = self._samplers.get(which)
+        if cached is not None and cached[1] == sig:
+            return cached[0]
+        self._free_sampler(which)
         cfg = _lib.DrmnetCfg()
         cfg.z_dim = self.zdim
         cfg.max_timesteps = int(self.max_timesteps)
@@ -281,13 +267,14 @@ class DRMNet(nn.Module):
         torch.cuda.current_stream(zp[0].device).synchronize()
         with torch.cuda.device(zp[0].device):
             _lib.check(_lib.lib().drm_drmnet_create(hi, hr, _lib.ptr_array(zp), C.byref(cfg), C.byref(h)))
-        self._sampler, self._sampler_sig = h, sig
+        self._samplers[which] = (h, sig)
         return h
 
-    def _free_sampler(self):
-        if getattr(self, "_sampler", None) is not None:
-            _lib.lib().drm_drmnet_destroy(self._sampler)
-            self._sampler = None
+    def _free_sampler(self, which=None):
+        for k in ([which] if which else list(getattr(self, "_samplers", {}))):
+            entry = self._samplers.pop(k, None)
+            if entry is not None:
+                _lib.lib().drm_drmnet_destroy(entry[0])
 
     def __del__(self):
         try:
@@ -376,36 +363,36 @@ class DRMNet(nn.Module):
     # ------------------------------------------------------------------ estimate.py glue
     @torch.no_grad()
     def get_input_for_predict(self, batch, bs: Optional[int] = None):
-        """drmnet.py:1011-1045: luminance geometric-mean scaling to refmap_input_scaler, ds.transform, conds = [LrK]."""
-        LrK = batch[self.input_key]
-        bs = min(len(LrK), bs) if bs is not None else len(LrK)
-        LrK = LrK[:bs]
-        if self.refmap_input_scaler is not None:
-            L = 0.212671 * LrK[:, 0] + 0.715160 * LrK[:, 1] + 0.072169 * LrK[:, 2]
-            self.normalizing_scale = self.refmap_input_scaler / torch.exp(
-                (torch.log(L.clip(1e-5)) * (L > 0)).sum(dim=(1, 2)) / (L > 0).sum(dim=(1, 2))
-            )
-            LrK = LrK * self.normalizing_scale[:, None, None, None]
-        LrK = self.ds.transform(LrK)
-        Lr0 = batch.get("Lr0")
-        if Lr0 is not None:
-            if self.refmap_input_scaler is not None:
-                Lr0 = Lr0[:bs] * self.normalizing_scale[:, None, None, None]
-            Lr0 = self.ds.transform(Lr0)
-        LrK = self.get_first_stage_encoding(self.encode_first_stage(LrK))
-        tag = batch["tag"][:bs]
-        cond_LrK = LrK
-        if self.sigma_for_cond_xK > 0:
-            cond_LrK = self.sigma_for_cond_xK * torch.randn_like(LrK) + cond_LrK
-        illnet_c = [cond_LrK]
-        refnet_c = illnet_c
-        return LrK, Lr0, illnet_c, refnet_c, tag
+        """models/drmnet.py:1011-1045: the first ``bs`` refmaps are exposure-normalised (each scaled so the geometric mean of its
+        luminance over lit pixels equals ``refmap_input_scaler``; the factors are kept in ``self.normalizing_scale`` for the way
+        back, scripts/estimate.py:99-100), mapped to network space by ``ds.transform`` and returned with the conditioning lists
+        of the two networks (the same tensor, optionally jittered by ``sigma_for_cond_xK``).  The luminance reduction and the
+        scale + log map run as two HIP launches (csrc/transform.hip)."""
+        from . import ops
+
+        src = batch[self.input_key]
+        n = len(src) if bs is None else min(len(src), bs)
+        scaled = self.refmap_input_scaler is not None
+
+        def to_network_space(x):
+            x = _lib.require_gpu_tensor(x[:n], self.input_key)
+            if scaled:
+                x = ops.map_chain(x, [("img_mul", 0.0)], scale=self.normalizing_scale)
+            return self.ds.transform(x)
+
+        if scaled:
+            self.normalizing_scale = ops.luminance_scale(_lib.require_gpu_tensor(src[:n], self.input_key), self.refmap_input_scaler)
+        LrK = self.get_first_stage_encoding(self.encode_first_stage(to_network_space(src)))
+        Lr0 = to_network_space(batch["Lr0"]) if batch.get("Lr0") is not None else None
+        cond = LrK if self.sigma_for_cond_xK <= 0 else self.sigma_for_cond_xK * torch.randn_like(LrK) + LrK
+        illnet_c = [cond]
+        return LrK, Lr0, illnet_c, illnet_c, batch["tag"][:n]
 
     def r0toenvmap(self, r0: torch.Tensor, envshape: Optional[Tuple[int]] = None) -> torch.Tensor:
-        """drmnet.py:931-941: divide by basis_r0, warp the mirror map to a lat-long envmap -> [B, H, W, 3]."""
-        from .transform import mirmap2envmap
+        """models/drmnet.py:931-941: r0 / basis_r0, warped from the mirror-ball parametrisation to a lat-long map, channels last
+        ([B, H, W, 3]) -- one HIP gather kernel (division fused into the fetch)."""
+        from . import ops
 
         if envshape is None:
             envshape = (self.image_size, self.image_size * 2)
-        r0 = r0 / self.basis_r0
-        return mirmap2envmap(r0, envshape).permute(0, 2, 3, 1)
+        return ops.mirmap2envmap(r0, envshape, basis=self.basis_r0.to(r0.device), channels_last=True)

@@ -56,10 +56,12 @@ def estimate(DRMNet_model, ObsNet_model, input_img: torch.Tensor, input_normal: 
 
 @torch.no_grad()
 def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_normals: torch.Tensor, masks: torch.Tensor,
-                   erode_kernel_size: int = 5, *, early_exit: bool = True, seed: Optional[int] = None):
+                   erode_kernel_size: int = 5, *, early_exit: bool = True, seed: Optional[int] = None, hooks: Optional[dict] = None):
     """`estimate` for B object images at once (BASELINE configs[4]: the chain batched the way the samplers like it):
     per-object erosion + refmap gather, then ONE ObsNet DDIM run and ONE DRMNet loop over the whole batch.
-    input_imgs / input_normals [B, H, W, 3], masks [B, H, W] bool  ->  (Lr0 [B, 3, res, res], zK [B, z_dim], K [B])."""
+    input_imgs / input_normals [B, H, W, 3], masks [B, H, W] bool  ->  (Lr0 [B, 3, res, res], zK [B, z_dim], K [B]).
+    `hooks` injects the random draws as in `estimate` (batched along dim 0 / dim 1 of the per-step tensors)."""
+    hooks = hooks or {}
     refmap_res = DRMNet_model.ds.size
     refmaps, refmasks = [], []
     for img, nrm, mask in zip(input_imgs, input_normals, masks):
@@ -70,15 +72,18 @@ def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_n
         refmasks.append(mk)
     B = len(refmaps)
     batch = {"tag": [f"obj{i}" for i in range(B)], "raw_refmap": torch.stack(refmaps), "raw_refmask": torch.stack(refmasks)}
-    c, _, _ = ObsNet_model.get_cond_for_predict(batch)
+    c, _, _ = ObsNet_model.get_cond_for_predict(batch, noise=hooks.get("cond_noise"))
     use_ddim = ObsNet_model.ddim_steps is not None
     extra = {} if seed is None else {"seed": seed}
+    obs_extra = {k: hooks[k] for k in ("x_T", "noise") if k in hooks}
     with ObsNet_model.ema_scope("Plotting"):
-        samples, _ = ObsNet_model.sample_log(cond=c, batch_size=B, ddim=use_ddim, ddim_steps=ObsNet_model.ddim_steps, eta=ObsNet_model.ddim_eta, **extra)
+        samples, _ = ObsNet_model.sample_log(cond=c, batch_size=B, ddim=use_ddim, ddim_steps=ObsNet_model.ddim_steps, eta=ObsNet_model.ddim_eta,
+                                             **extra, **obs_extra)
     inpaint = ObsNet_model.ds.rescale(ObsNet_model.decode_first_stage(samples))
     LrK, _, illnet_c, refnet_c, _ = DRMNet_model.get_input_for_predict({"tag": batch["tag"], "LrK": inpaint})
+    loop_extra = {k: hooks[k] for k in ("noise0", "step_noise") if k in hooks}
     with DRMNet_model.ema_scope():
-        samples, zK_est, K = DRMNet_model.p_sample_loop(LrK, illnet_c, refnet_c, verbose=False, early_exit=early_exit, **extra)
+        samples, zK_est, K = DRMNet_model.p_sample_loop(LrK, illnet_c, refnet_c, verbose=False, early_exit=early_exit, **extra, **loop_extra)
     Lr0 = DRMNet_model.ds.rescale(DRMNet_model.decode_first_stage(samples)).clip(0)
     if DRMNet_model.refmap_input_scaler is not None:
         Lr0 = Lr0 / DRMNet_model.normalizing_scale[:, None, None, None]

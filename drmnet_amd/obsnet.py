@@ -11,8 +11,6 @@ Mirrors (inference half only; training, VQ/KL first stages, patch fold/unfold ar
 from __future__ import annotations
 
 import ctypes as C
-from contextlib import contextmanager
-from functools import partial
 from typing import Dict, List, Optional, Union
 
 import numpy as np
@@ -21,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from .config import instantiate_from_config
-from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma
+from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma, ema_weights, load_checkpoint
 
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
@@ -62,6 +60,7 @@ class DDPM(nn.Module):
         self.channels = channels
         self.use_positional_encodings = use_positional_encodings
         self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self._weight_set = "live"
         self.use_ema = use_ema
         if self.use_ema:
             self.model_ema = LitEma(self.model)
@@ -84,60 +83,43 @@ class DDPM(nn.Module):
         return self.betas.device
 
     def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
-        """fp64 numpy tables cast to fp32 buffers, ddpm.py:137-187 (same names, same order)."""
-        betas = given_betas if given_betas is not None else make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end, cosine_s)
-        alphas = 1.0 - betas
-        alphas_cumprod = np.cumprod(alphas, axis=0)
-        alphas_cumprod_prev = np.append(1.0, alphas_cumprod[:-1])
-        (timesteps,) = betas.shape
-        self.num_timesteps = int(timesteps)
-        self.linear_start = linear_start
-        self.linear_end = linear_end
-        to_torch = partial(torch.tensor, dtype=torch.float32)
-        self.register_buffer("betas", to_torch(betas))
-        self.register_buffer("alphas_cumprod", to_torch(alphas_cumprod))
-        self.register_buffer("alphas_cumprod_prev", to_torch(alphas_cumprod_prev))
-        self.register_buffer("sqrt_alphas_cumprod", to_torch(np.sqrt(alphas_cumprod)))
-        self.register_buffer("sqrt_one_minus_alphas_cumprod", to_torch(np.sqrt(1.0 - alphas_cumprod)))
-        self.register_buffer("log_one_minus_alphas_cumprod", to_torch(np.log(1.0 - alphas_cumprod)))
-        self.register_buffer("sqrt_recip_alphas_cumprod", to_torch(np.sqrt(1.0 / alphas_cumprod)))
-        self.register_buffer("sqrt_recipm1_alphas_cumprod", to_torch(np.sqrt(1.0 / alphas_cumprod - 1)))
-        posterior_variance = (1 - self.v_posterior) * betas * (1.0 - alphas_cumprod_prev) / (1.0 - alphas_cumprod) + self.v_posterior * betas
-        self.register_buffer("posterior_variance", to_torch(posterior_variance))
-        self.register_buffer("posterior_log_variance_clipped", to_torch(np.log(np.maximum(posterior_variance, 1e-20))))
-        self.register_buffer("posterior_mean_coef1", to_torch(betas * np.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod)))
-        self.register_buffer("posterior_mean_coef2", to_torch((1.0 - alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - alphas_cumprod)))
+        """ldm/models/diffusion/ddpm.py:137-187: every table of the forward / posterior process is computed in fp64 numpy from the
+        betas and registered as an fp32 buffer -- same names, same order, so ``state_dict()`` matches the reference's checkpoints
+        (tests/golden/ddpm_schedule.npz pins the values bit for bit).  abar_t = prod(1 - beta); posterior q(x_{t-1} | x_t, x_0)
+        has variance beta_t (1 - abar_{t-1}) / (1 - abar_t) (mixed with beta_t by v_posterior) and mean coefficients
+        beta_t sqrt(abar_{t-1}) / (1 - abar_t) on x_0 and (1 - abar_{t-1}) sqrt(alpha_t) / (1 - abar_t) on x_t."""
+        beta = given_betas if given_betas is not None else make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end, cosine_s)
+        (n_steps,) = beta.shape
+        self.num_timesteps = int(n_steps)
+        self.linear_start, self.linear_end = linear_start, linear_end
+        alpha = 1.0 - beta
+        abar = np.cumprod(alpha, axis=0)
+        abar_prev = np.append(1.0, abar[:-1])
+        post_var = (1 - self.v_posterior) * beta * (1.0 - abar_prev) / (1.0 - abar) + self.v_posterior * beta
+        tables = (  # (buffer name, fp64 table) in the reference's registration order
+            ("betas", beta),
+            ("alphas_cumprod", abar),
+            ("alphas_cumprod_prev", abar_prev),
+            ("sqrt_alphas_cumprod", np.sqrt(abar)),
+            ("sqrt_one_minus_alphas_cumprod", np.sqrt(1.0 - abar)),
+            ("log_one_minus_alphas_cumprod", np.log(1.0 - abar)),
+            ("sqrt_recip_alphas_cumprod", np.sqrt(1.0 / abar)),
+            ("sqrt_recipm1_alphas_cumprod", np.sqrt(1.0 / abar - 1)),
+            ("posterior_variance", post_var),
+            ("posterior_log_variance_clipped", np.log(np.maximum(post_var, 1e-20))),  # the variance is 0 at t = 0
+            ("posterior_mean_coef1", beta * np.sqrt(abar_prev) / (1.0 - abar)),
+            ("posterior_mean_coef2", (1.0 - abar_prev) * np.sqrt(alpha) / (1.0 - abar)),
+        )
+        for name, table in tables:
+            self.register_buffer(name, torch.tensor(table, dtype=torch.float32))
 
-    @contextmanager
     def ema_scope(self, context=None):
-        if self.use_ema:
-            self.model_ema.store(self.model.parameters())
-            self.model_ema.copy_to(self.model)
-            if context is not None:
-                print(f"{context}: Switched to EMA weights")
-        try:
-            yield None
-        finally:
-            if self.use_ema:
-                self.model_ema.restore(self.model.parameters())
-                if context is not None:
-                    print(f"{context}: Restored training weights")
+        """ldm/models/diffusion/ddpm.py:189-202 -- ``with model.ema_scope(): ...`` samples with the EMA weights (wrappers.ema_weights)."""
+        return ema_weights(self, [(self.model, self.model_ema)] if self.use_ema else [], context)
 
     def init_from_ckpt(self, path, ignore_keys=list(), only_model=False, verbose=True):
-        sd = torch.load(path, map_location="cpu")
-        if "state_dict" in list(sd.keys()):
-            sd = sd["state_dict"]
-        for k in list(sd.keys()):
-            for ik in ignore_keys:
-                if k.startswith(ik):
-                    print("Deleting key {} from state_dict.".format(k))
-                    del sd[k]
-        missing, unexpected = self.load_state_dict(sd, strict=False) if not only_model else self.model.load_state_dict(sd, strict=False)
-        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
-        if len(missing) > 0 and verbose:
-            print(f"Missing Keys: {missing}")
-        if len(unexpected) > 0 and verbose:
-            print(f"Unexpected Keys: {unexpected}")
+        """ddpm.py:204-231 / models/obsnet.py:139-160 (``only_model`` loads into the wrapped U-Net alone)."""
+        load_checkpoint(self, path, ignore_keys, into=self.model if only_model else None, verbose=verbose)
 
     def predict_start_from_noise(self, x_t, t, noise):
         return (extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t

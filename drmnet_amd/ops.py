@@ -105,3 +105,106 @@ def randn(shape, seed: int, offset: int = 0, device="cuda"):
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().drm_randn(out.data_ptr(), out.numel(), seed, offset, _lib.stream_ptr(out.device)))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ boundary maps (csrc/transform.hip)
+
+MAP_CODES = {"log_p1": 0, "log10": 1, "lowerbound": 2, "unit_to_signed": 3, "norm_log": 4, "exp_m1": 5, "exp10": 6, "signed_to_unit": 7,
+             "denorm_log": 8, "img_mul": 9, "img_div": 10, "clip0": 11}
+MAX_CHAIN = 8
+
+
+def _per_image(x: torch.Tensor):
+    """[B, C, H, W] -> (B, C*H*W); a 3-D [C, H, W] tensor is one image (the reference reduces over the last three dims)."""
+    if x.ndim < 3:
+        raise RuntimeError("expected a [(B,) C, H, W] tensor")
+    b = 1
+    for d in x.shape[:-3]:
+        b *= int(d)
+    return b, x.numel() // max(b, 1)
+
+
+@torch.no_grad()
+def map_chain(x, steps, lo=None, hi=None, scale=None, out=None):
+    """Applies ``steps`` = [(map name, scalar argument), ...] to every element in ONE pass (drm_map_chain).
+    lo / hi / scale: per-image fp32 vectors for the maps that need them.  Longer chains are cut into passes of 8."""
+    import ctypes as C
+
+    x = _lib.require_gpu_tensor(x, "x")
+    b, per = _per_image(x)
+    vec = lambda t, n: None if t is None else _lib.require_gpu_tensor(t.reshape(-1), n)
+    lo, hi, scale = vec(lo, "lo"), vec(hi, "hi"), vec(scale, "scale")
+    for n, t in (("lo", lo), ("hi", hi), ("scale", scale)):
+        if t is not None and t.numel() != b:
+            raise RuntimeError(f"{n} must have one entry per image ({b}), got {t.numel()}")
+    res = torch.empty_like(x) if out is None else out
+    src = x
+    steps = list(steps)
+    if not steps:
+        res.copy_(x)
+        return res
+    with _dev(x):
+        for k in range(0, len(steps), MAX_CHAIN):
+            part = steps[k:k + MAX_CHAIN]
+            ops_arr = (C.c_int32 * len(part))(*[MAP_CODES[n] for n, _ in part])
+            arg_arr = (C.c_float * len(part))(*[float(a) for _, a in part])
+            _lib.check(_lib.lib().drm_map_chain(src.data_ptr(), res.data_ptr(), per, b, ops_arr, arg_arr, len(part), _lib.ptr(lo), _lib.ptr(hi),
+                                                _lib.ptr(scale), _lib.stream_ptr(x.device)))
+            src = res
+    return res
+
+
+@torch.no_grad()
+def masked_log_range(x, mask):
+    """(log10 min, log10 max) per image of x under mask, the dynamic_normalize statistics of basedataset.py:63-69 -> two [B] tensors."""
+    x = _lib.require_gpu_tensor(x, "x")
+    b, per = _per_image(x)
+    hw = x.shape[-1] * x.shape[-2]
+    mask = _lib.require_gpu_tensor(mask.to(torch.float32), "mask")
+    if mask.numel() != b * hw:
+        raise NotImplementedError("mask must be [B, 1, H, W] (one plane per image, broadcast over channels)")
+    lo = torch.empty((b,), dtype=torch.float32, device=x.device)
+    hi = torch.empty_like(lo)
+    with _dev(x):
+        _lib.check(_lib.lib().drm_masked_log_range(x.data_ptr(), mask.data_ptr(), b, per // hw, hw, lo.data_ptr(), hi.data_ptr(), _lib.stream_ptr(x.device)))
+    return lo, hi
+
+
+@torch.no_grad()
+def luminance_scale(x, scaler: float):
+    """models/drmnet.py:1020-1026: scaler / geometric-mean luminance over the lit pixels, per image of x [B, 3, H, W] -> [B]."""
+    x = _lib.require_gpu_tensor(x, "x")
+    if x.ndim != 4 or x.shape[1] != 3:
+        raise RuntimeError("luminance_scale expects [B, 3, H, W]")
+    out = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        _lib.check(_lib.lib().drm_luminance_scale(x.data_ptr(), x.shape[0], x.shape[2] * x.shape[3], float(scaler), out.data_ptr(), _lib.stream_ptr(x.device)))
+    return out
+
+
+@torch.no_grad()
+def mirmap2envmap(mirmap, output_shape, basis=None, log_scale_interpolation=False, channels_last=False):
+    """utils/transform.py:106-144 (+ the basis_r0 division of DRMNet.r0toenvmap when ``basis`` [C, H, W] is given)."""
+    mirmap = _lib.require_gpu_tensor(mirmap, "mirmap")
+    b, c, h, w = mirmap.shape
+    oh, ow = int(output_shape[0]), int(output_shape[1])
+    if basis is not None:
+        basis = _lib.require_gpu_tensor(basis.expand(c, h, w), "basis_r0")
+    out = torch.empty((b, oh, ow, c) if channels_last else (b, c, oh, ow), dtype=torch.float32, device=mirmap.device)
+    with _dev(mirmap):
+        _lib.check(_lib.lib().drm_mirmap2envmap(mirmap.data_ptr(), _lib.ptr(basis), out.data_ptr(), b, c, h, w, oh, ow, int(bool(log_scale_interpolation)),
+                                                int(bool(channels_last)), _lib.stream_ptr(mirmap.device)))
+    return out
+
+
+@torch.no_grad()
+def hdr2ldr(x, mask=None, alpha: float = 0.18, gamma: float = 2.2):
+    """utils/tonemap.py:4-9 on a [H, W, 3] device tensor (mask: optional [H, W] bool / uint8)."""
+    x = _lib.require_gpu_tensor(x, "x")
+    if x.ndim != 3 or x.shape[2] != 3:
+        raise RuntimeError("hdr2ldr expects [H, W, 3]")
+    m = None if mask is None else _lib.require_gpu_tensor(mask.to(torch.uint8), "mask", torch.uint8)
+    out = torch.empty_like(x)
+    with _dev(x):
+        _lib.check(_lib.lib().drm_hdr2ldr(x.data_ptr(), _lib.ptr(m), x.shape[0] * x.shape[1], float(alpha), float(gamma), out.data_ptr(), _lib.stream_ptr(x.device)))
+    return out

@@ -100,7 +100,10 @@ class _HipUNetBase(nn.Module):
         _lib.check(L.drm_unet_create(C.byref(d), C.byref(h)))
         self._h = h
         self._ws = _lib.Workspace()
-        self._loaded_sig = None
+        # engine-side weight sets (include/drmnet_hip.h "Weight sets"): 0 = this module's parameters, 1 = an EMA shadow
+        self._set_sig = {"live": None, "ema": None}
+        self._active_set = "live"
+        self._ema_source: Optional[List[torch.Tensor]] = None
         self.precision = "fp32"
         # parameter table straight from the engine == reference state_dict() order
         n = L.drm_unet_param_count(h)
@@ -144,7 +147,7 @@ class _HipUNetBase(nn.Module):
             raise ValueError(f"precision must be one of {list(self.PRECISIONS)}")
         _lib.check(_lib.lib().drm_unet_set_precision(self._h, self.PRECISIONS[precision]))
         self.precision = precision
-        self._loaded_sig = None
+        self._set_sig = {"live": None, "ema": None}
         return self
 
     # ------------------------------------------------------------------ weights
@@ -152,20 +155,38 @@ class _HipUNetBase(nn.Module):
         sd = dict(self.named_parameters())
         return [sd[k] for k in self._keys]
 
+    SETS = {"live": 0, "ema": 1}
+
+    def use_weights(self, which: str, tensors: Optional[Sequence[torch.Tensor]] = None) -> None:
+        """Selects the packed weight image the next forwards read.  "live" = this module's own parameters; "ema" = ``tensors``
+        (the LitEma shadow buffers in parameter order).  Each image is packed once and re-packed only when its source tensors
+        change (storage or in-place version), so ``ema_scope`` enter / exit moves no weights -- the engine-side answer to the
+        reference's copy-in / copy-back (ldm/modules/ema.py:46-76)."""
+        if which not in self.SETS:
+            raise ValueError(f"weight set must be one of {list(self.SETS)}")
+        if which == "ema":
+            if tensors is None or len(tensors) != len(self._keys):
+                raise RuntimeError("use_weights('ema') needs one shadow tensor per parameter, in parameter order")
+            self._ema_source = list(tensors)
+        self._active_set = which
+
     def sync_weights(self, force: bool = False) -> None:
-        """(Re)upload parameters to the engine when they changed (load_state_dict, ema_scope swap, .to(device))."""
-        ps = self.param_tensors()
+        """Makes the engine's active weight image current: (re)packs it when its source tensors changed (load_state_dict,
+        .to(device), an optimizer step, a new EMA shadow) and selects it."""
+        which = self._active_set
+        ps = self.param_tensors() if which == "live" else self._ema_source
         sig = (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)
-        if not force and sig == self._loaded_sig:
-            return
-        dev = ps[0].device
-        for k, p in zip(self._keys, ps):
-            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
-                raise RuntimeError(f"parameter {k} must be a contiguous fp32 tensor on one GPU (got {p.device}, {p.dtype}); call .cuda() first")
-        arr = _lib.ptr_array(ps)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().drm_unet_load_params(self._h, arr, len(ps), _lib.stream_ptr(dev)))
-        self._loaded_sig = sig
+        L = _lib.lib()
+        if force or sig != self._set_sig[which]:
+            dev = ps[0].device
+            for k, p in zip(self._keys, ps):
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                    raise RuntimeError(f"parameter {k} must be a contiguous fp32 tensor on one GPU (got {p.device}, {p.dtype}); call .cuda() first")
+            arr = _lib.ptr_array(ps)
+            with torch.cuda.device(dev):
+                _lib.check(L.drm_unet_load_params_set(self._h, self.SETS[which], arr, len(ps), _lib.stream_ptr(dev)))
+            self._set_sig[which] = sig
+        _lib.check(L.drm_unet_use_set(self._h, self.SETS[which]))
 
     def engine_handle(self):
         self.sync_weights()

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 1
+#define DRM_ABI_VERSION 2
 #define DRM_MAX_LEVELS 8
 
 int drm_abi_version(void);
@@ -60,6 +60,16 @@ int drm_unet_param_info(const drm_unet* net, int index, char* name, int name_cap
  * Replaces nn.Module.load_state_dict + LitEma.copy_to (ldm/modules/ema.py:46-53): the host passes the
  * EMA tensors when sampling under ema_scope. May be called again to swap weights. */
 int drm_unet_load_params(drm_unet* net, const float* const* ptrs, int count, void* stream);
+
+/* Weight sets.  A handle keeps DRM_WEIGHT_SETS packed images side by side: set 0 for the module's live parameters, set 1 for
+ * the EMA shadow that ema_scope swaps in around sampling (models/drmnet.py:242-258, ldm/models/diffusion/ddpm.py:189-202,
+ * ldm/modules/ema.py:46-76).  Each set is packed (and, in the f16 modes, pre-split) once by drm_unet_load_params_set;
+ * drm_unet_use_set selects the one the following forwards / sampler calls read -- entering and leaving the scope moves no
+ * weights.  drm_unet_load_params loads into the currently selected set.  The selection is part of the handle's state: calls that
+ * use one handle from several threads must agree on it. */
+#define DRM_WEIGHT_SETS 2
+int drm_unet_load_params_set(drm_unet* net, int set, const float* const* ptrs, int count, void* stream);
+int drm_unet_use_set(drm_unet* net, int set);
 
 /* Arithmetic of the convolution / projection kernels:
  *   0 = DRM_PREC_FP32 : v_mfma_f32_32x32x2_f32, exact fp32 products (default)
@@ -193,6 +203,44 @@ int drm_refmap_mask_make(const float* colors, const float* normals, int64_t n, i
 /* Mask erosion of scripts/estimate.py:43-50: a mask pixel is dropped when a non-mask pixel lies inside the disk
  * footprint of diameter kernel_size around it (zero "same" padding: the image border does not erode).  uint8 0/1, [H][W]. */
 int drm_erode_mask(const uint8_t* mask, int H, int W, int kernel_size, uint8_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The elementwise maps either side of the samplers, and the envmap warp / tone map after them.
+ * ------------------------------------------------------------------------------------------- */
+/* BaseDataset.transform / rescale (dataset/basedataset.py:29-112): a transform_func string such as
+ * "resize_0p1tom1p1_normalizedLogarithmic_lowerbound1e-6" is a chain of named maps (applied right to left; rescale applies
+ * the inverses left to right).  drm_map_chain applies up to 8 maps per element in one pass: x, out [B][per_image] fp32
+ * (out may alias x), ops[n_ops] the DRM_MAP_* codes in application order, args[n_ops] their scalar argument.
+ *   lo / hi : fp32[B] per-image (log10 min, log10 max) of "normalizedLogarithmic" (NULL unless DRM_MAP_NORM_LOG / _DENORM_LOG is used)
+ *   scale   : fp32[B] per-image factor of DRM_MAP_IMG_MUL / _IMG_DIV (DRMNet.normalizing_scale, models/drmnet.py:1020-1027;
+ *             scripts/estimate.py:99-100) */
+#define DRM_MAP_LOG_P1 0          /* "log":    log10(x + 0.1) + 1                                   basedataset.py:52-53  */
+#define DRM_MAP_LOG10 1           /* "log10":  log10(x)                                             :54-55                */
+#define DRM_MAP_LOWERBOUND 2      /* "lowerbound<b>": clip(x, min = arg)                            :56-58                */
+#define DRM_MAP_UNIT_TO_SIGNED 3  /* "0p1tom1p1": 2 x - 1                                           :59-60                */
+#define DRM_MAP_NORM_LOG 4        /* "normalizedLogarithmic": (log10 x - lo[b]) / (hi[b] - lo[b])   :61-76                */
+#define DRM_MAP_EXP_M1 5          /* inverse of "log":  10^min(x - 1, arg) - 0.1  (arg = clamp_before_exp, +inf = none)  :88-92 */
+#define DRM_MAP_EXP10 6           /* inverse of "log10": 10^min(x, arg)                             :93-97                */
+#define DRM_MAP_SIGNED_TO_UNIT 7  /* inverse of "0p1tom1p1": (x + 1) / 2                            :100-101              */
+#define DRM_MAP_DENORM_LOG 8      /* x (hi[b] - lo[b]) + lo[b]  (followed by DRM_MAP_EXP10)         :102-112              */
+#define DRM_MAP_IMG_MUL 9         /* x * scale[b] */
+#define DRM_MAP_IMG_DIV 10        /* x / scale[b] */
+#define DRM_MAP_CLIP0 11          /* clip(x, min = 0)                                               scripts/estimate.py:97 */
+int drm_map_chain(const float* x, float* out, int64_t per_image, int B, const int32_t* ops, const float* args, int n_ops, const float* lo,
+                  const float* hi, const float* scale, void* stream);
+/* dynamic_normalize branch of "normalizedLogarithmic" (basedataset.py:63-69): per image b of x [B][C][HW] with mask [B][HW]
+ * (fp32 0/1, broadcast over channels): linearmax = max(x mask); hi[b] = log10(linearmax); lo[b] = log10(min(x mask + (1 - mask) linearmax)). */
+int drm_masked_log_range(const float* x, const float* mask, int B, int C, int HW, float* lo, float* hi, void* stream);
+/* models/drmnet.py:1020-1026: scale[b] = scaler / exp(mean over {L > 0} of log(clip(L, 1e-5))), L = Rec.709 luminance of x[b] ([B][3][HW]). */
+int drm_luminance_scale(const float* x, int B, int HW, float scaler, float* scale, void* stream);
+/* mirmap2envmap (utils/transform.py:106-144; view +z, top +y, zenith +y, left edge -z, reverse_azimuth -- the only configuration
+ * the reference supports) fused with the basis_r0 division of DRMNet.r0toenvmap (models/drmnet.py:931-941; basis [C][H][W] or
+ * NULL): mirmap [B][C][H][W] -> out [B][C][OH][OW], or [B][OH][OW][C] when channels_last (what r0toenvmap returns).
+ * Bilinear, border padding, align_corners = False (torch.nn.functional.grid_sample arithmetic). */
+int drm_mirmap2envmap(const float* mirmap, const float* basis, float* out, int B, int C, int H, int W, int OH, int OW, int log_scale_interpolation,
+                      int channels_last, void* stream);
+/* hdr2ldr (utils/tonemap.py:4-9): x [HW][3] one channels-last image, mask uint8[HW] or NULL -> out [HW][3] in [0, 1]. */
+int drm_hdr2ldr(const float* x, const uint8_t* mask, int HW, float alpha, float gamma, float* out, void* stream);
 
 #ifdef __cplusplus
 }

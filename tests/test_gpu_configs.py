@@ -1,0 +1,172 @@
+"""GPU checks at the BASELINE configurations that round 1 left untested (VERDICT r01 "untested configs"):
+
+* ObsNet (the 1000-step / DDIM network, configs[1] and configs[2]) at batch 32 and batch 256 of 3x128x256, in the fp32-accurate
+  split mode and in the reduced-precision `f16` mode: every probed row against the reference golden, batch permutation;
+* IllNet at batch 32 in exact-fp32 mode against the golden;
+* the first two DDIM (eta = 1) and ancestral DDPM steps of the full-width ObsNet at 3x128x256 against outputs recorded from the
+  reference's p_sample_ddim / p_sample (tests/golden/full_obsnet_sampler_steps.npz), device loop and host-driven per-step calls;
+* a batch-32 DDIM step / 3-step ancestral run: device loop == host-driven steps;
+* estimate_batch on B replicated objects == B x estimate.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, gold, rel_l2
+from drmnet_amd import synth
+from oracle import unet as ou
+from test_gpu_nets import build, full_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(GOLD))
+TOL = {"fp32": 2e-5, "f16x3": 2e-5, "f16": 5e-3}  # f16 is the reduced-precision mode with its own stated tolerance
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no fallback)"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,precision", [(32, "f16x3"), (32, "f16"), (256, "f16x3"), (256, "f16")])
+def test_obsnet_metric_shape_batches(dev, B, precision):
+    gd = gold("full_obsnet_128x256")
+    m = build(ou.OBSNET_CFG, "unet", int(gd["seed"]), dev).set_precision(precision)
+    xc, _ = full_inputs(1, 128, 256)
+    t = torch.from_numpy(gd["t"]).to(dev)
+    xb = xc.repeat(B, 1, 1, 1).to(dev)
+    xb[1::2] = xb[1::2].flip(-1)  # odd rows see a different (valid) input: a row mix-up cannot cancel out
+    out = m(xb, t.repeat(B))
+    assert tuple(out.shape) == (B, 3, 128, 256) and torch.isfinite(out).all()
+    for r in (0, 2, B // 2, B - 2):
+        e = rel_l2(out[r].cpu(), gd["out"][0])
+        assert e < TOL[precision], (r, e)
+    assert rel_l2(out[1].cpu(), out[B - 1].cpu()) < 1e-6
+    if B == 32:
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(dev)
+        outp = m(xb[perm], t.repeat(B))
+        assert rel_l2(outp.cpu(), out[perm].cpu()) < 1e-6
+    del m, out, xb
+    torch.cuda.empty_cache()
+
+
+def test_illnet_batch32_exact_fp32_mode(dev):
+    gd = gold("full_illnet_128x256")
+    m = build(ou.ILLNET_CFG, "unet", int(gd["seed"]), dev).set_precision("fp32")
+    xc, t_emb = full_inputs(1, 128, 256)
+    B = 32
+    out = m(xc.repeat(B, 1, 1, 1).to(dev), t_emb=t_emb.repeat(B, 1).to(dev))
+    for r in (0, 13, 31):
+        e = rel_l2(out[r].cpu(), gd["out"][0])
+        assert e < TOL["fp32"], (r, e)
+    del m, out
+    torch.cuda.empty_cache()
+
+
+def full_obsnet(dev, precision):
+    from drmnet_amd.config import instantiate_from_config, load_config
+
+    cfg = load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["model"]
+    cfg["params"].pop("ckpt_path")
+    cfg["params"]["use_ema"] = False
+    m = instantiate_from_config(cfg)
+    synth.load_synth(m.model.diffusion_model, synth.SEED_OBSNET)
+    return m.to(dev).set_precision(precision)
+
+
+def sampler_inputs(g):
+    gen = torch.Generator().manual_seed(int(g["gen_seed"]))
+    cond = synth.synth_refmaps(1, 128, 256, synth.SEED_INPUT) * 2 - 1
+    x_T = torch.randn((1, 3, 128, 256), generator=gen)
+    noise = torch.randn((2, 1, 3, 128, 256), generator=gen)
+    return cond, x_T, noise
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_full_width_sampler_steps_vs_reference(dev, precision):
+    from drmnet_amd.ddim import DDIMSampler
+
+    g = gold("full_obsnet_sampler_steps")
+    m = full_obsnet(dev, precision)
+    cond, x_T, noise = (t.to(dev) for t in sampler_inputs(g))
+    s = DDIMSampler(m)
+    for k in (1, 2):
+        x, _ = s.sample(50, 1, (3, 128, 256), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, num_steps=k)
+        e = rel_l2(x.cpu(), g["ddim_x"][k - 1])
+        print(f"full-width ddim ({precision}) after {k} step(s): {e:.2e}")
+        assert e < 1e-4
+    # ancestral: the device loop walks t = T-1 .. 0 for `start_T` steps from the top only when T == start_T, so the two reference
+    # steps (t = 999, 998) are taken through the per-step drop-in p_sample (same fused update kernel)
+    img = x_T
+    for j, t in enumerate((999, 998)):
+        img, x0 = m.p_sample(img, [cond], torch.full((1,), t, dtype=torch.long, device=dev), clip_denoised=False, return_x0=True, noise=noise[j])
+        e = rel_l2(img.cpu(), g["ddpm_x"][j])
+        print(f"full-width ddpm ({precision}) t={t}: {e:.2e}")
+        assert e < 1e-4
+        assert rel_l2(x0.cpu(), g["ddpm_pred_x0"][j]) < 2e-3  # x_recon amplifies eps by sqrt(1/abar - 1) ~ 1e8 at t = 999
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_batch32_ddim_and_ddpm_device_loop_vs_host_steps(dev):
+    """B = 32 @128x256 on the full-width ObsNet: one DDIM step and a 3-step ancestral run, device loops (drm_ddim_sample /
+    drm_ddpm_sample with injected noise) against the same steps driven from the host through the reference-named per-step
+    methods (apply_model + the reference's update arithmetic in torch on the device tensors)."""
+    from drmnet_amd.ddim import DDIMSampler
+
+    m = full_obsnet(dev, "f16x3")
+    B = 32
+    gen = torch.Generator().manual_seed(123)
+    cond = (synth.synth_refmaps(B, 128, 256, 7) * 2 - 1).to(dev)
+    x_T = torch.randn((B, 3, 128, 256), generator=gen).to(dev)
+    noise = torch.randn((3, B, 3, 128, 256), generator=gen).to(dev)
+    s = DDIMSampler(m)
+    x, _ = s.sample(50, B, (3, 128, 256), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, num_steps=1)
+    c = s.ddim_coef[49]
+    t = torch.full((B,), int(s.ddim_timesteps[49]), dtype=torch.long, device=dev)
+    e = m.apply_model(x_T, t, [cond])
+    pred = (x_T - float(c[1]) * e) / float(c[0])
+    x_host = float(c[2]) * pred + float(c[3]) * e + float(c[4]) * noise[0]
+    assert torch.isfinite(x).all() and rel_l2(x.cpu(), x_host.cpu()) < 1e-5
+    # ancestral, the last three timesteps (t = 2, 1, 0: includes the noise-free final step)
+    pred_x0, inter = m.p_sample_loop(cond, (B, 3, 128, 256), return_intermediates=True, x_T=x_T, verbose=False, start_T=3, noise=noise)
+    img = x_T
+    for j, tt in enumerate((2, 1, 0)):
+        img, x0 = m.p_sample(img, [cond], torch.full((B,), tt, dtype=torch.long, device=dev), return_x0=True, noise=noise[j])
+    assert rel_l2(inter["x_inter"][-1].cpu(), img.cpu()) < 1e-5 and rel_l2(pred_x0.cpu(), x0.cpu()) < 1e-5
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_estimate_batch_equals_replicated_estimate(dev):
+    """scripts/estimate.py:29-102 batched: B copies of data/sample through estimate_batch == estimate on one copy, row by row
+    (Philox noise keyed by (seed, element): the single-image run is row 0 of the same stream)."""
+    from drmnet_amd import file_io
+    from drmnet_amd.estimate import estimate, estimate_batch
+    from test_gpu_estimate import tiny_models
+
+    g = gold("estimate_chain")
+    drm, obs = tiny_models(g, dev)
+    drm.set_precision("f16x3")
+    obs.set_precision("f16x3")
+    d = os.path.join(GOLD, "sample")
+    img = file_io.load_exr(os.path.join(d, "image.exr"), as_torch=True).to(dev)
+    nrm = torch.from_numpy(np.load(os.path.join(d, "normal.npy"))).to(dev)
+    mask = torch.logical_and(file_io.load_png(os.path.join(d, "mask.png"), as_torch=True).to(dev) > 0, torch.linalg.norm(nrm, dim=-1) > 0.5)
+    B = 4
+    hooks = {"cond_noise": torch.from_numpy(g["cond"]).to(dev), "x_T": torch.from_numpy(g["x_T"]).to(dev), "noise": torch.from_numpy(g["noise"]).to(dev),
+             "noise0": torch.from_numpy(g["noise0"]).to(dev), "step_noise": torch.from_numpy(g["step_noise"]).to(dev)}
+    Lr0_1, zK_1 = estimate(drm, obs, img, nrm, mask, hooks=hooks)
+    rep = lambda t: t.repeat(B, *([1] * (t.ndim - 1))) if t.shape[0] == 1 else t
+    bh = {"cond_noise": rep(hooks["cond_noise"]), "x_T": rep(hooks["x_T"]), "noise": hooks["noise"].repeat(1, B, 1, 1, 1),
+          "noise0": rep(hooks["noise0"]), "step_noise": hooks["step_noise"].repeat(1, B, 1, 1, 1)}
+    Lr0_b, zK_b, K_b = estimate_batch(drm, obs, img[None].repeat(B, 1, 1, 1), nrm[None].repeat(B, 1, 1, 1), mask[None].repeat(B, 1, 1), hooks=bh)
+    assert tuple(Lr0_b.shape) == (B,) + tuple(Lr0_1.shape)
+    for b in range(B):
+        assert rel_l2(Lr0_b[b].cpu(), Lr0_1.cpu()) < 1e-5, b
+        assert np.allclose(zK_b[b].cpu().numpy(), zK_1.cpu().numpy(), atol=1e-5, equal_nan=True)
+    assert K_b.tolist() == [int(g["K"][0])] * B
+    # and the whole batch still matches the reference trace at the north-star tolerance
+    assert rel_l2(Lr0_b[B - 1].cpu(), g["Lr0"]) < 1e-4

@@ -47,30 +47,76 @@ def test_obsnet_yaml_instantiates_and_state_dict_matches_reference(obsnet, manif
     assert obsnet.ddim_steps == 50 and obsnet.ddim_eta == 1.0 and obsnet.num_timesteps == 1000 and obsnet.clip_denoised is False
 
 
-def test_dataset_plugin_and_transforms():
+def test_dataset_plugin_loads_from_the_reference_yaml():
+    from drmnet_amd.dataset import BaseDataset
+
     ds = instantiate_from_config(model_cfg("configs/drmnet/eval_drmnet.yaml")["data"]["params"]["predict"])
-    x = torch.rand(2, 3, 128, 128) * 3
-    y = ds.transform(x)
-    assert torch.allclose(y, torch.log10(x + 0.1) + 1)
-    assert torch.allclose(ds.rescale(y), x, atol=1e-5)
+    assert isinstance(ds, BaseDataset) and ds.size == 128 and ds.transform_func_str == "log" and ds.clamp_before_exp == 20
     ds2 = instantiate_from_config(load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["data"]["params"]["predict"])
-    m = (torch.rand(2, 1, 128, 128) > 0.5).float()
-    z = ds2.transform(x.clamp_min(1e-3), dynamic_normalize=True, mask=m)
-    assert float((z * m).max()) <= 1.0 + 1e-5 and float((z * m + (1 - m)).min()) >= -1.0 - 1e-5
-    assert torch.allclose(ds2.rescale(z), x.clamp_min(1e-3), rtol=1e-4, atol=1e-5)
+    assert ds2.transform_func_str == "resize_0p1tom1p1_normalizedLogarithmic_lowerbound1e-6"
+    with pytest.raises(RuntimeError):  # the maps are HIP kernels: CPU tensors fail loudly
+        ds.transform(torch.rand(2, 3, 128, 128))
 
 
-def test_ema_scope_swaps_and_restores(drmnet):
+def test_ema_scope_swaps_parameters_and_selects_the_ema_weight_set(drmnet):
+    """models/drmnet.py:242-258: inside the scope the module parameters hold the EMA values (as in the reference) AND both
+    engines are pointed at their EMA weight image, whose source tensors are the shadow buffers themselves."""
+    ill = drmnet.illnet_model.diffusion_model
     p = next(drmnet.illnet_model.parameters())
     before = p.detach().clone()
-    shadow = drmnet.illnet_model_ema.state_dict()
-    name = drmnet.illnet_model_ema.m_name2s_name[next(iter(dict(drmnet.illnet_model.named_parameters())))]
-    shadow_t = dict(drmnet.illnet_model_ema.named_buffers())[name]
+    first = next(iter(dict(drmnet.illnet_model.named_parameters())))
+    shadow_t = getattr(drmnet.illnet_model_ema, drmnet.illnet_model_ema.m_name2s_name[first])
     shadow_t.add_(1.0)
+    assert drmnet._weight_set == "live" and ill._active_set == "live"
     with drmnet.ema_scope():
         assert torch.equal(p, shadow_t)
+        assert drmnet._weight_set == "ema" and ill._active_set == "ema" and drmnet.refnet_model.diffusion_model._active_set == "ema"
+        src = ill._ema_source
+        assert len(src) == len(ill._keys)
+        assert src[0].data_ptr() == getattr(drmnet.illnet_model_ema, "diffusion_model" + ill._keys[0].replace(".", "")).data_ptr()
     assert torch.equal(p, before)
+    assert drmnet._weight_set == "live" and ill._active_set == "live"
     shadow_t.sub_(1.0)
+    with pytest.raises(ZeroDivisionError):  # the scope restores on exceptions too
+        with drmnet.ema_scope():
+            1 / 0
+    assert drmnet._weight_set == "live" and torch.equal(p, before)
+
+
+def synth_reference_checkpoint(model, path, seed):
+    """A checkpoint in the reference's layout: {"state_dict": {...}} with the live parameters, the LitEma shadow
+    buffers under their dot-less names and num_updates / decay, as pytorch_lightning writes it for models/drmnet.py / ddpm.py."""
+    g = torch.Generator().manual_seed(seed)
+    weights = {k for k, _ in model.named_parameters()}
+    sd = {}
+    for k, v in model.state_dict().items():
+        is_shadow = "_ema." in k and not k.endswith((".decay", ".num_updates"))
+        if k in weights or is_shadow:
+            sd[k] = torch.randn(v.shape, generator=g) * (0.05 if is_shadow else 0.02)
+        else:
+            sd[k] = v.clone()  # schedule tables, z0, EMA bookkeeping: persistent buffers with their true values
+    torch.save({"state_dict": sd, "epoch": 3, "global_step": 1234, "pytorch-lightning_version": "1.9.0"}, path)
+    return sd
+
+
+def test_init_from_ckpt_loads_reference_layout(tmp_path, drmnet, obsnet, capsys):
+    for model, seed, ema_attr, ema_key in ((drmnet, 5, "illnet_model_ema", "illnet_model_ema.diffusion_modelinput_blocks00weight"),
+                                           (obsnet, 6, "model_ema", "model_ema.diffusion_modelinput_blocks00weight")):
+        path = str(tmp_path / f"m{seed}.ckpt")
+        original = {k: v.clone() for k, v in model.state_dict().items()}
+        sd = synth_reference_checkpoint(model, path, seed)
+        assert ema_key in sd and any(k.endswith("_ema.num_updates") or k == "model_ema.num_updates" for k in sd)
+        model.init_from_ckpt(path, ignore_keys=["first_stage_model"])
+        out = capsys.readouterr().out
+        assert "with 0 missing and 0 unexpected keys" in out
+        got = model.state_dict()
+        for k in (ema_key, [k for k in sd if k.endswith("input_blocks.0.0.weight")][0]):
+            assert torch.equal(got[k], sd[k]), k
+        # ignore_keys drops by prefix and reports what it dropped
+        model.init_from_ckpt(path, ignore_keys=[ema_attr])
+        out = capsys.readouterr().out
+        assert f"Deleting key {ema_key} from state_dict." in out and " 0 unexpected keys" in out and "Missing Keys" in out
+        model.load_state_dict(original)  # the fixtures are shared with the other tests of this module
 
 
 def test_product_schedule_tables_bit_exact(obsnet):

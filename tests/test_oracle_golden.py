@@ -213,3 +213,36 @@ def test_ddpm_trace():
     assert rel_l2(imgs[0], g["x_inter"][0]) < TOL
     assert rel_l2(img, g["x_inter"][-1]) < 1e-4
     assert rel_l2(pred_x0, g["pred_x0"]) < 1e-4
+
+
+def full_sampler_inputs():
+    """Regenerates the seeded inputs of tests/golden/full_obsnet_sampler_steps.npz (tools/make_golden.py make_full_samplers)."""
+    g = gold("full_obsnet_sampler_steps")
+    gen = torch.Generator().manual_seed(int(g["gen_seed"]))
+    cond = synth.synth_refmaps(1, 128, 256, synth.SEED_INPUT) * 2 - 1
+    x_T = torch.randn((1, 3, 128, 256), generator=gen)
+    noise = torch.randn((2, 1, 3, 128, 256), generator=gen)
+    assert synth.checksum(x_T) == pytest.approx(float(g["xT_sum"]), rel=1e-12)
+    return g, cond, x_T, noise
+
+
+def test_full_width_sampler_steps():
+    """Two DDIM (eta = 1) and two ancestral steps of the full-width ObsNet at 3x128x256 against the reference's p_sample_ddim /
+    p_sample outputs (ddim.py:206-259, ddpm.py:1120-1167)."""
+    g, cond, x_T, noise = full_sampler_inputs()
+    P = params(ou.OBSNET_CFG, "unet", int(g["seed"]))
+    topo = ou.build_topology(ou.OBSNET_CFG, "unet")
+    S = osamp.ddpm_schedule(1000, 1e-4, 0.09)
+    d = osamp.ddim_schedule(S["alphas_cumprod"], 1000, 50, 1.0)
+    eps_model = lambda xc, t: ou.unet_forward(P, topo, xc, timesteps=t)
+    x, xs = osamp.ddim_sample(eps_model, cond, x_T, noise, d, num_steps=2)
+    assert rel_l2(xs[0], g["ddim_x"][0]) < TOL and rel_l2(xs[1], g["ddim_x"][1]) < 5 * TOL
+    # ancestral: t = 999, 998 only (ddpm_sample walks T-1 .. 0, so drive the two steps by hand with the same arithmetic)
+    img = x_T
+    for j, t in enumerate((999, 998)):
+        e = eps_model(torch.cat([img, cond], dim=1), torch.full((1,), t, dtype=torch.long))
+        x_recon = S["sqrt_recip_alphas_cumprod"][t] * img - S["sqrt_recipm1_alphas_cumprod"][t] * e
+        mean = S["posterior_mean_coef1"][t] * x_recon + S["posterior_mean_coef2"][t] * img
+        img = mean + (0.5 * S["posterior_log_variance_clipped"][t]).exp() * noise[j]
+        assert rel_l2(img, g["ddpm_x"][j]) < 5 * TOL, j
+        assert rel_l2(x_recon, g["ddpm_pred_x0"][j]) < 1e-3, j  # x_recon amplifies eps by sqrt(1/abar - 1) ~ 1e8 at t = 999

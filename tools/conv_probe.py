@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times single conv layers through the op-level ABI with the library profiler (kernel time only).
-usage: python tools/conv_probe.py [precision] ; DRM_DBG=<bits> selects experiment switches in the split kernel."""
+usage: python tools/conv_probe.py [precision]."""
 import ctypes as C, math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,6 +30,6 @@ for (n, cin, cout, h, w, k) in shapes:
     ms, fl, by, cnt = (C.c_double * K)(), (C.c_double * K)(), (C.c_double * K)(), (C.c_int64 * K)()
     L.drm_profile_collect(ms, fl, by, cnt)
     i = 0 if k == 3 else 1
-    print(f"{prec} dbg={os.environ.get('DRM_DBG','0')} conv{k}x{k} {cin}->{cout} @{h}x{w} B={n}: {ms[i]/cnt[i]:.3f} ms  {fl[i]/ms[i]/1e9:.1f} TF", flush=True)
+    print(f"{prec} conv{k}x{k} {cin}->{cout} @{h}x{w} B={n}: {ms[i]/cnt[i]:.3f} ms  {fl[i]/ms[i]/1e9:.1f} TF", flush=True)
     del x, wt
     torch.cuda.empty_cache()

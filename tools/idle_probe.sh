@@ -1,9 +1,11 @@
 #!/bin/bash
 # GPU busy fraction of a bench workload: sum of kernel durations (rocprofv3 kernel trace) / wall time of the timed steps
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+mkdir -p "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/idle_probe; rm -rf $OUT
-rocprofv3 --kernel-trace --stats -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-profile --no-parity-check > $OUT.log 2>&1
-cd $GRAFT_REPO_ROOT
+OUT="$ROOT/gpurun_out/idle_probe"; rm -rf "$OUT"
+rocprofv3 --kernel-trace --stats -d "$OUT" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline --no-profile --no-parity-check > "$OUT.log" 2>&1
+cd "$ROOT"
 python3 - <<'PY'
 import sqlite3, glob, json
 db = sorted(glob.glob('gpurun_out/idle_probe/**/*_results.db', recursive=True))[-1]

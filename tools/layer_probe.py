@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times ResBlocks through the op-level ABI (NHWC inside, realistic epilogues); DRM_DBG selects experiment switches."""
+"""Times ResBlocks through the op-level ABI (NHWC inside, realistic epilogues)."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,5 +23,5 @@ for (n, cin, cout, h, w) in [(32, 128, 128, 128, 256), (32, 256, 256, 64, 128)]:
     torch.cuda.synchronize(); L.drm_profile_enable(0)
     K = 5; ms, fl, by, cnt = (C.c_double*K)(), (C.c_double*K)(), (C.c_double*K)(), (C.c_int64*K)()
     L.drm_profile_collect(ms, fl, by, cnt)
-    print(f"{prec} dbg={os.environ.get('DRM_DBG','0')} resblock {cin}->{cout} @{h}x{w}: conv3x3 {ms[0]/cnt[0]:.3f} ms/launch ({fl[0]/ms[0]/1e9:.0f} TF)", flush=True)
+    print(f"{prec} resblock {cin}->{cout} @{h}x{w}: conv3x3 {ms[0]/cnt[0]:.3f} ms/launch ({fl[0]/ms[0]/1e9:.0f} TF)", flush=True)
     del x, P; torch.cuda.empty_cache()

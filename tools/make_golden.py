@@ -317,6 +317,118 @@ def make_obsnet_samplers():
         refddim.noise_like, refddpm.noise_like = o1, o2
 
 
+def make_full_samplers():
+    """Full-width ObsNet (configs/obsnet/eval_obsnet.yaml, 147.6 M parameters by the synth rule) at the metric shape 3x128x256:
+    the first two DDIM steps (eta = 1; ddim.py:206-259 p_sample_ddim at index 49, 48) and the first two ancestral steps
+    (ddpm.py:1120-1167 p_sample at t = 999, 998) from a given x_T with the per-step draws injected.  Only inputs that cannot be
+    regenerated (none: everything is seeded) and the reference's outputs are stored."""
+    import ldm.models.diffusion.ddim as refddim
+    import ldm.models.diffusion.ddpm as refddpm
+
+    _, OBS, DDIM, _ = rh.ref_classes()
+    cfg = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    cfg.update(use_ema=False)
+    m = OBS(**cfg).eval()
+    cs = load_rule(m.model.diffusion_model, synth.SEED_OBSNET)
+    B, h, w = 1, 128, 256
+    g = gen(61)
+    cond = synth.synth_refmaps(B, h, w, synth.SEED_INPUT) * 2 - 1
+    x_T = torch.randn((B, 3, h, w), generator=g)
+    noise = torch.randn((2, B, 3, h, w), generator=g)
+    ctr = {"i": 0}
+
+    def noise_like(shape, device, repeat=False):
+        out = noise[ctr["i"]]
+        ctr["i"] += 1
+        assert tuple(out.shape) == tuple(shape)
+        return out
+
+    o1, o2 = refddim.noise_like, refddpm.noise_like
+    refddim.noise_like = noise_like
+    refddpm.noise_like = noise_like
+    try:
+        s = DDIM(m)
+        s.make_schedule(ddim_num_steps=50, ddim_eta=1.0, verbose=False)
+        x = x_T
+        xs, p0 = [], []
+        t0 = time.time()
+        with torch.no_grad():
+            for index in (49, 48):
+                ts = torch.full((B,), int(s.ddim_timesteps[index]), dtype=torch.long)
+                x, pred = s.p_sample_ddim(x, cond, ts, index=index)
+                xs.append(x)
+                p0.append(pred)
+        ctr["i"] = 0
+        y = x_T
+        ys, q0 = [], []
+        with torch.no_grad():
+            for t in (999, 998):
+                y, x0 = m.p_sample(y, cond, torch.full((B,), t, dtype=torch.long), clip_denoised=m.clip_denoised, return_x0=True)
+                ys.append(y)
+                q0.append(x0)
+        print(f"  full-width sampler steps: {time.time() - t0:.1f}s  ddim |x| {float(xs[-1].abs().max()):.3e}  ddpm |x| {float(ys[-1].abs().max()):.3e}")
+    finally:
+        refddim.noise_like, refddpm.noise_like = o1, o2
+    save("full_obsnet_sampler_steps", ddim_x=torch.stack(xs), ddim_pred_x0=torch.stack(p0), ddpm_x=torch.stack(ys), ddpm_pred_x0=torch.stack(q0),
+         seed=synth.SEED_OBSNET, wsum=cs, gen_seed=61, cond_sum=synth.checksum(cond), xT_sum=synth.checksum(x_T))
+
+
+def make_transforms():
+    """The elementwise maps either side of the samplers and the envmap warp / tone map after them, from the reference's own
+    functions: BaseDataset.transform / rescale for both shipped transform_func strings (dataset/basedataset.py:29-112),
+    DRMNet.get_input_for_predict's exposure scaling (models/drmnet.py:1017-1034), mirmap2envmap (utils/transform.py:106-144),
+    DRMNet.r0toenvmap (models/drmnet.py:931-941) and hdr2ldr (utils/tonemap.py:4-9).  Inputs are seeded and stored (small)."""
+    rh.install_stubs()
+    from dataset.basedataset import BaseDataset
+    from utils.tonemap import hdr2ldr
+    from utils.transform import mirmap2envmap
+
+    g = gen(71)
+    out = {}
+    # --- "log" (DRMNet dataset): HDR radiance -> network space and back, with the clamp of the shipped config and without
+    hdr = torch.exp(torch.randn((3, 3, 16, 24), generator=g) * 1.5 - 2.0)
+    hdr[0, 0, 0, :4] = 0.0
+    net = torch.randn((3, 3, 16, 24), generator=g) * 1.5
+    net[1, 1, 2, :3] = torch.tensor([25.0, 21.5, -30.0])  # above / below the clamp_before_exp = 20 of the shipped config
+    ds = BaseDataset(size=16, transform_func="log", clamp_before_exp=20)
+    out.update(log_x=hdr, log_y=ds.transform(hdr), log_net=net, log_rescaled=ds.rescale(net))
+    out["log_rescaled_noclamp"] = BaseDataset(size=16, transform_func="log", clamp_before_exp=0.0).rescale(net.clamp(max=30))
+    # --- ObsNet's string: lower bound, per-image masked log normalisation, [0,1] -> [-1,1]; resize is a no-op at the stored size
+    ds2 = BaseDataset(size=16, transform_func="resize_0p1tom1p1_normalizedLogarithmic_lowerbound1e-6", clamp_before_exp=20)
+    x2 = torch.exp(torch.randn((3, 3, 16, 16), generator=g) * 2.0 - 3.0)
+    x2[0, :, :2] = 0.0  # below the lower bound
+    m2 = (torch.rand((3, 1, 16, 16), generator=g) > 0.4).float()
+    y2 = ds2.transform(x2, dynamic_normalize=True, mask=m2)
+    lo, hi = ds2.Logarithmic_params
+    net2 = torch.rand((3, 3, 16, 16), generator=g) * 2.4 - 1.2
+    out.update(nl_x=x2, nl_mask=m2, nl_y=y2, nl_lo=lo, nl_hi=hi, nl_net=net2, nl_rescaled=ds2.rescale(net2))
+    x3 = x2[0]  # 3-D input: one image, statistics over all three dims
+    y3 = ds2.transform(x3, dynamic_normalize=True, mask=m2[0])
+    out.update(nl3_y=y3, nl3_lo=ds2.Logarithmic_params[0], nl3_hi=ds2.Logarithmic_params[1])
+    # --- exposure normalisation of get_input_for_predict
+    drm = tiny_drmnet(gamma=0.9, epsilon=1.0, max_timesteps=3)
+    drm.ds = BaseDataset(size=16, transform_func="log", clamp_before_exp=20)
+    lrk = torch.exp(torch.randn((4, 3, 16, 16), generator=g) * 1.2 - 1.0)
+    lrk[2, :, 5:9, 5:9] = 0.0  # unlit pixels are left out of the geometric mean
+    LrK, _, illc, refc, tag = drm.get_input_for_predict({"LrK": lrk, "tag": ["a", "b", "c", "d"]}, bs=3)
+    out.update(gi_x=lrk, gi_LrK=LrK, gi_scale=drm.normalizing_scale, gi_scaler=drm.refmap_input_scaler)
+    # --- mirror map -> envmap, r0toenvmap, tone map
+    mir = torch.exp(torch.randn((2, 3, 16, 16), generator=g) * 0.8)
+    out.update(mir=mir, env=mirmap2envmap(mir, (16, 32)), env_log=mirmap2envmap(mir, (16, 32), log_scale_interpolation=True),
+               env_odd=mirmap2envmap(mir[:1], (10, 28)))
+    mir128 = torch.exp(torch.randn((1, 3, 128, 128), generator=gen(72)) * 0.5)
+    out.update(env128=mirmap2envmap(mir128, (128, 256)), mir128_seed=72)
+    basis = torch.rand((3, 16, 16), generator=g) + 0.5
+    drm.basis_r0 = basis
+    out.update(basis=basis, r0env=drm.r0toenvmap(mir, (16, 32)))
+    envh = out["env"][0].permute(1, 2, 0).clone().numpy()
+    envh[:2] *= 1e-6  # unlit rows (L <= 5e-5) are left out of the mean
+    msk = (torch.rand((16, 32), generator=g) > 0.3).numpy()
+    out.update(ldr_x=envh, ldr=hdr2ldr(envh), ldr_mask=msk, ldr_masked=hdr2ldr(envh, msk), ldr_a=hdr2ldr(envh, alpha=0.3, gamma=1.8))
+    save("transforms", **out)
+
+
 def make_refmap():
     """refmap_mask_make (utils/img2refmap.py:6-37) and the mask erosion of scripts/estimate.py:43-50 on the reference's own
     data/sample inputs.  The three sample files are DATA and are copied next to the fixtures (tests/golden/sample/); the EXR
@@ -487,6 +599,8 @@ STEPS = {
     "drmnet_loop": lambda oa: make_drmnet_loop(),
     "obsnet_samplers": lambda oa: make_obsnet_samplers(),
     "full": lambda oa: make_full_nets(oa),
+    "full_samplers": lambda oa: make_full_samplers(),
+    "transforms": lambda oa: make_transforms(),
 }
 
 

@@ -187,6 +187,73 @@ __global__ __launch_bounds__(512) void k_rand_bf16(float* out, int iters, float 
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// 16x16x32 twin of k_rand<1>: the same 64x64 per-wave product (4 A fragments x 4 B fragments, hi and lo planes, three MFMAs
+// per 16x16 output block = 48 MFMAs per 32-deep slab) on rotating pseudo-random fp16 operands.  MI355X_MICROARCH.md "DVFS
+// give-back" item 7 reports the 16x16x32 bf16 shape holding a higher clock than 32x32x16 at equal cycles per FLOP.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k_rand16(float* out, int iters, float seed) {
+  f32x4v acc[16];
+  for (int i = 0; i < 16; ++i)
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  f16x8 fr[16];  // 0-3 ah, 4-7 al, 8-11 bh, 12-15 bl
+  for (int k = 0; k < 16; ++k)
+    for (int e = 0; e < 8; ++e) {
+      const unsigned hsh = hash32((blockIdx.x * blockDim.x + threadIdx.x) * 128u + k * 8u + e + (unsigned)seed);
+      fr[k][e] = (_Float16)(((int)(hsh & 0xffff) - 32768) * (1.0f / 16384.0f));
+    }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[i * 4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[4 + i], fr[8 + c], acc[i * 4 + c], 0, 0, 0);
+        acc[i * 4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[i], fr[12 + c], acc[i * 4 + c], 0, 0, 0);
+        acc[i * 4 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[i], fr[8 + c], acc[i * 4 + c], 0, 0, 0);
+      }
+    const f16x8 t = fr[0];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) fr[k] = fr[k + 1];
+    fr[15] = t;
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i)
+    for (int e = 0; e < 4; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// 32x32x16 with the same 64x64x32 slab per iteration (2 slabs x 12 MFMAs) for a like-for-like comparison
+__global__ __launch_bounds__(512) void k_rand32(float* out, int iters, float seed) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  f16x8 fr[16];  // slab s: 8s + {0,1 ah; 2,3 al; 4,5 bh; 6,7 bl}
+  for (int k = 0; k < 16; ++k)
+    for (int e = 0; e < 8; ++e) {
+      const unsigned hsh = hash32((blockIdx.x * blockDim.x + threadIdx.x) * 128u + k * 8u + e + (unsigned)seed);
+      fr[k][e] = (_Float16)(((int)(hsh & 0xffff) - 32768) * (1.0f / 16384.0f));
+    }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          acc[i * 2 + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[8 * s2 + 2 + i], fr[8 * s2 + 4 + c], acc[i * 2 + c], 0, 0, 0);
+          acc[i * 2 + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[8 * s2 + i], fr[8 * s2 + 6 + c], acc[i * 2 + c], 0, 0, 0);
+          acc[i * 2 + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[8 * s2 + i], fr[8 * s2 + 4 + c], acc[i * 2 + c], 0, 0, 0);
+        }
+    const f16x8 t = fr[0];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) fr[k] = fr[k + 1];
+    fr[15] = t;
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename K>
 static void run(const char* name, K kern, int threads, int blocks, int iters, double flop_per_mfma, int accs, float* out, double secs) {
   hipEvent_t e0, e1;
@@ -216,6 +283,16 @@ int main(int argc, char** argv) {
   float* out;
   hipMalloc(&out, 4096 * 512 * 4);
   const double F16 = 2.0 * 32 * 32 * 16, F32 = 2.0 * 32 * 32 * 2;
+  if (argc > 2 && atoi(argv[2]) == 16) {  // MFMA shape comparison only: 64x64x32 slab per iteration in both shapes
+    const double F1616 = 2.0 * 16 * 16 * 32;
+    for (int rep = 0; rep < 3; ++rep) {
+      run("f16 32x32x16 slab, 2 w/SIMD", k_rand32, 512, 256, 15000, F16, 24, out, secs);
+      run("f16 16x16x32 slab, 2 w/SIMD", k_rand16, 512, 256, 15000, F1616, 48, out, secs);
+      run("f16 32x32x16 slab, 1 w/SIMD", k_rand32, 256, 256, 30000, F16, 24, out, secs);
+      run("f16 16x16x32 slab, 1 w/SIMD", k_rand16, 256, 256, 30000, F1616, 48, out, secs);
+    }
+    return 0;
+  }
   run("f16 32x32x16, 1 wave/SIMD", k_f16<4>, 256, 256, 200000, F16, 4, out, secs);
   run("f16 32x32x16, 2 waves/SIMD", k_f16<4>, 512, 256, 100000, F16, 4, out, secs);
   run("f16 dep distance 1, 1 w/SIMD", k_dep<1>, 256, 256, 60000, F16, 12, out, secs);

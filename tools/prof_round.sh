@@ -4,10 +4,10 @@
 # PMC passes (FETCH_SIZE, WRITE_SIZE) for the HBM traffic of the dominant kernels.
 #   usage: tools/prof_round.sh <tag>        e.g. tools/prof_round.sh r01
 tag=${1:-r01}
-ROOT=$GRAFT_REPO_ROOT
-OUT=$ROOT/gpurun_out/prof_round
-rm -rf $OUT; mkdir -p $OUT
-cd $ROOT
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+OUT="$ROOT/gpurun_out/prof_round"
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd "$ROOT"
 python3 bench.py > $OUT/${tag}_bench_f16x3.log 2>&1
 grep "^{\"metric\"" $OUT/${tag}_bench_f16x3.log | tail -1 > $OUT/${tag}_bench_f16x3.json
 cd /tmp && export TMPDIR=/tmp

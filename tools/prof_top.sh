@@ -1,9 +1,11 @@
 #!/bin/bash
 # rocprofv3 kernel stats of a short bench run; prints the top kernels (name, calls, total ms, avg us)
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+mkdir -p "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_top
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_top -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_top.log 2>&1
-cd $GRAFT_REPO_ROOT
+rm -rf "$ROOT/gpurun_out/prof_top"
+rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/prof_top" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$ROOT/gpurun_out/prof_top.log" 2>&1
+cd "$ROOT"
 python3 - <<'PY'
 import sqlite3, glob
 db = sorted(glob.glob('gpurun_out/prof_top/**/*_results.db', recursive=True))[-1]
