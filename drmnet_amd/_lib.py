@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdrmnet_hip.so")
+# DRM_LIB_PATH: an explicitly named alternative build (tools/stamp_probe.sh uses it for its diagnostic library); never set by the product
+LIB_PATH = os.environ.get("DRM_LIB_PATH") or os.path.join(_HERE, "csrc", "libdrmnet_hip.so")
 ABI_VERSION = 2
 MAX_LEVELS = 8
 

@@ -79,6 +79,10 @@ struct ConvArgs {
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
   int ksplit = 1;                      // split-K factor (conv_split_ksplit); > 1: partial results are added into `out`
   int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 1 = plain fp16 operands
+#ifdef DRM_S2_STAMP
+  unsigned* stamp_out = nullptr;       // diagnostic build: [8 waves][128][2] (id, s_memtime low word) of one workgroup
+  int stamp_block = 0, stamp_tile0 = 0;
+#endif
   double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)
   const float* w_inv_scale = nullptr;  // split-precision path: device scalar 2^-k undoing the weight pre-scaling
 };

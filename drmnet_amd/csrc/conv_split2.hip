@@ -26,6 +26,28 @@
 #include "common.h"
 #include "profiler.h"
 
+// Diagnostic build only (tools/stamp_probe.sh, -DDRM_S2_STAMP, a separate .so): one workgroup records an s_memtime timeline of
+// its waves (cdna_hip_programming.md 7 "In-kernel stamps") into the 8 KiB of LDS the main 3x3 variant leaves free; it leaves the
+// kernel through a buffer nothing else reads.  The product library compiles every S2_STAMP to nothing.
+#ifdef DRM_S2_STAMP
+#define S2_STAMP(id)                                                                               \
+  do {                                                                                             \
+    if (stamp_on && stamp_n < 128) {                                                               \
+      unsigned long long t_;                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      if (lane == 0) {                                                                             \
+        stamp_lds[(wave * 128 + stamp_n) * 2] = (unsigned)(id);                                    \
+        stamp_lds[(wave * 128 + stamp_n) * 2 + 1] = (unsigned)t_;                                  \
+      }                                                                                            \
+      ++stamp_n;                                                                                   \
+    }                                                                                              \
+  } while (0)
+#else
+#define S2_STAMP(id) do { } while (0)
+#endif
+
 namespace drm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -180,6 +202,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   int k_tile = jx;  // index inside this XCD's range
   if (k_tile >= x_count) return;
   TilePos cur = decode(x_start + k_tile);
+#ifdef DRM_S2_STAMP
+  unsigned* stamp_lds = reinterpret_cast<unsigned*>(lds + C::LDS_F4);  // [NW][128][2]
+  int stamp_n = 0;
+  int stamp_tiles = 0;
+  bool stamp_on = false;
+  if (a.stamp_out && (int)blockIdx.x == a.stamp_block)
+    for (int k = tid; k < C::NW * 256; k += C::NTHR) stamp_lds[k] = 0;
+#endif
 
   const int Ctot = a.C0 + a.C1;
   // split-K (deep, small maps: too few output tiles to fill the chip, long K): blockIdx.y owns a contiguous range of the
@@ -389,6 +419,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   while (true) {
     const bool has_next = k_tile + J < x_count;
     const TilePos nxt = has_next ? decode(x_start + k_tile + J) : cur;
+#ifdef DRM_S2_STAMP
+    stamp_on = a.stamp_out && (int)blockIdx.x == a.stamp_block && stamp_tiles >= a.stamp_tile0;
+    ++stamp_tiles;
+    S2_STAMP(1);  // tile start
+#endif
     // One tap (or 32-channel slab pair) of MFMAs: LDS fragment reads + 3 MFMAs per 32x32x16 product
     auto mma_tap = [&](const float4* Ab, const float4* Bc, int tapoff, auto&& hook) {
 #pragma unroll
@@ -513,33 +548,45 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             });
           }
         };
+        S2_STAMP(2);  // step start
         compute();
+        S2_STAMP(3);  // MFMAs + interleaved DMA / activation requests issued
         ++step;
         constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
         if (last_g) {
           if (a_next) {
             __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
+            S2_STAMP(4);  // barrier 1 of the chunk end passed
             wait_vmcnt<C::G_PER * (C::NG - 1 - A_G)>();  // the request of group A_G; younger: the weight groups issued after it
+            S2_STAMP(5);  // activation loads landed
             store_A(As);
+            S2_STAMP(6);  // staged (GroupNorm affine + SiLU + split + LDS writes)
             wait_vmcnt<BASE>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            S2_STAMP(7);  // next weight group landed
             __builtin_amdgcn_s_barrier();
+            S2_STAMP(8);  // barrier 2 passed
           } else {
             wait_vmcnt<BASE>();
+            S2_STAMP(7);
             __builtin_amdgcn_s_barrier();
+            S2_STAMP(8);
           }
         } else {
           // the activation loads were issued right after the group of step (A_G)+R-1: they are younger than the next
           // group while g - A_G <= R-2
           if (a_younger && a_next) wait_vmcnt<BASE + C::A_CNT>();
           else wait_vmcnt<BASE>();
+          S2_STAMP(7);
           __builtin_amdgcn_s_barrier();
+          S2_STAMP(8);
         }
       });
     }
 
     }
 
+    S2_STAMP(9);  // epilogue start
     // ---- epilogue of the current tile.  Rows of a 32x32 accumulator tile held by this lane: 8g + 4h + k (g, k = 0..3);
     // the four k rows are four consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per
     // (i, g).  Loads are issued unconditionally on clamped addresses (batched ahead of the math); stores are predicated
@@ -632,11 +679,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    S2_STAMP(10);  // tile end (epilogue + statistics fold done)
     if (!has_next) break;
     k_tile += J;
     cur = nxt;
   }
   wait_vmcnt<0>();  // drain the tail DMAs before the workgroup's LDS can be re-assigned
+#ifdef DRM_S2_STAMP
+  if (a.stamp_out && (int)blockIdx.x == a.stamp_block) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int k = tid; k < C::NW * 256; k += C::NTHR) a.stamp_out[k] = stamp_lds[k];
+  }
+#endif
 }
 
 template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
@@ -674,6 +729,34 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     prof_tag(a.N, a.H, a.W, a.C0 + a.C1, a.Cout);
     ProfScope ps(TAPS == 9 ? PROF_CONV3 : PROF_CONV1, 2.0 * px * TAPS * cin * cout,
                  4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
+#ifdef DRM_S2_STAMP
+    // DRM_S2_STAMP_FILE=<path> [DRM_S2_STAMP_BLOCK=<workgroup>] [DRM_S2_STAMP_TILE0=<first recorded tile>]: appends one record
+    // per 8-wave launch that has the 8 KiB of LDS to spare
+    static const char* stamp_file = getenv("DRM_S2_STAMP_FILE");
+    if (stamp_file && C::NW == 8 && lds_bytes + 8192 <= di->lds_per_cu) {
+      static unsigned* dbuf = nullptr;
+      if (!dbuf) DRM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 8192));
+      DRM_HIP_CHECK(hipMemsetAsync(dbuf, 0, 8192, s));
+      ConvArgs at = a;
+      at.stamp_out = dbuf;
+      at.stamp_block = getenv("DRM_S2_STAMP_BLOCK") ? atoi(getenv("DRM_S2_STAMP_BLOCK")) : 8;
+      at.stamp_tile0 = getenv("DRM_S2_STAMP_TILE0") ? atoi(getenv("DRM_S2_STAMP_TILE0")) : 2;
+      DRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes + 8192));
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes + 8192, s, at);
+      DRM_HIP_CHECK(hipStreamSynchronize(s));
+      std::vector<unsigned> h(2048);
+      DRM_HIP_CHECK(hipMemcpy(h.data(), dbuf, 8192, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(stamp_file, "a")) {
+        fprintf(f, "launch taps %d tile %dx%d C %d->%d map %dx%d N %d grid %lld\n", TAPS, TH, TW, a.C0 + a.C1, a.Cout, a.H, a.W, a.N, grid);
+        for (int w = 0; w < 8; ++w) {
+          fprintf(f, "wave %d:", w);
+          for (int k = 0; k < 128 && h[(w * 128 + k) * 2]; ++k) fprintf(f, " %u:%u", h[(w * 128 + k) * 2], h[(w * 128 + k) * 2 + 1]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+    } else
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes, s, a);
   }
   DRM_HIP_CHECK(hipGetLastError());

@@ -81,12 +81,17 @@ def test_envmap_warp_and_tonemap_vs_reference(dev):
 
     g = gold("transforms")
     mir = T(g["mir"], dev)
-    assert rel_l2(mirmap2envmap(mir, (16, 32)).cpu(), g["env"]) < 2e-6
-    assert rel_l2(mirmap2envmap(mir, (16, 32), log_scale_interpolation=True).cpu(), g["env_log"]) < 2e-6
-    assert rel_l2(mirmap2envmap(mir[:1].contiguous(), (10, 28)).cpu(), g["env_odd"]) < 2e-6
+    # Stated tolerance 1e-5 rel-L2: the sample position goes through sin / cos / atan2 / acos (device libm vs the host's, an ulp or
+    # two apart) and is then scaled by W/2 pixels; on these white-noise test images (O(1) change per pixel) that is a few 1e-6.
+    WARP_TOL = 1e-5
+    assert rel_l2(mirmap2envmap(mir, (16, 32)).cpu(), g["env"]) < WARP_TOL
+    assert rel_l2(mirmap2envmap(mir, (16, 32), log_scale_interpolation=True).cpu(), g["env_log"]) < WARP_TOL
+    assert rel_l2(mirmap2envmap(mir[:1].contiguous(), (10, 28)).cpu(), g["env_odd"]) < WARP_TOL
     mir128 = torch.exp(torch.randn((1, 3, 128, 128), generator=torch.Generator().manual_seed(int(g["mir128_seed"]))) * 0.5)
-    assert rel_l2(mirmap2envmap(mir128.to(dev), (128, 256)).cpu(), g["env128"]) < 2e-6
-    assert rel_l2(ops.mirmap2envmap(mir, (16, 32), basis=T(g["basis"], dev), channels_last=True).cpu(), g["r0env"]) < 2e-6
+    assert rel_l2(mirmap2envmap(mir128.to(dev), (128, 256)).cpu(), g["env128"]) < WARP_TOL
+    assert rel_l2(ops.mirmap2envmap(mir, (16, 32), basis=T(g["basis"], dev), channels_last=True).cpu(), g["r0env"]) < WARP_TOL
+    smooth = torch.linspace(0.5, 2.0, 128)[None, None, :, None] * torch.linspace(1.0, 3.0, 128)[None, None, None, :] * torch.ones(2, 3, 1, 1)
+    assert rel_l2(mirmap2envmap(smooth.contiguous().to(dev), (128, 256)).cpu(), ot.mirmap2envmap(smooth, (128, 256))) < 1e-6  # a smooth map: 1e-6
     assert np.abs(hdr2ldr(g["ldr_x"]) - g["ldr"]).max() < 2e-6
     assert np.abs(hdr2ldr(g["ldr_x"], g["ldr_mask"]) - g["ldr_masked"]).max() < 2e-6
     assert np.abs(hdr2ldr(g["ldr_x"], alpha=0.3, gamma=1.8) - g["ldr_a"]).max() < 2e-6
