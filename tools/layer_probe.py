@@ -5,6 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drmnet_amd import _lib, ops, synth
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+zero = len(sys.argv) > 2 and sys.argv[2] == "zero"  # all-zero operands: same instruction stream, (almost) no datapath toggling -> what DVFS gives back
 ops.set_precision(prec)
 L = _lib.lib(); dev = torch.device("cuda:0")
 def man(cin, cout):
@@ -17,11 +18,13 @@ for (n, cin, cout, h, w) in [(32, 128, 128, 128, 256), (32, 256, 256, 64, 128)]:
     P = [p.to(dev) for p in synth.synth_state_dict(man(cin, cout), 1).values()]
     g = torch.Generator().manual_seed(0)
     x = torch.randn((n, cin, h, w), generator=g).to(dev); emb = torch.randn((n, 512), generator=g).to(dev)
+    if zero:
+        P = [torch.zeros_like(p) for p in P]; x = torch.zeros_like(x); emb = torch.zeros_like(emb)
     ops.resblock(P, x, emb); torch.cuda.synchronize()
     L.drm_profile_reset(); L.drm_profile_enable(1)
     for _ in range(3): ops.resblock(P, x, emb)
     torch.cuda.synchronize(); L.drm_profile_enable(0)
     K = 5; ms, fl, by, cnt = (C.c_double*K)(), (C.c_double*K)(), (C.c_double*K)(), (C.c_int64*K)()
     L.drm_profile_collect(ms, fl, by, cnt)
-    print(f"{prec} resblock {cin}->{cout} @{h}x{w}: conv3x3 {ms[0]/cnt[0]:.3f} ms/launch ({fl[0]/ms[0]/1e9:.0f} TF)", flush=True)
+    print(f"{prec}{' ZERO operands' if zero else ''} resblock {cin}->{cout} @{h}x{w}: conv3x3 {ms[0]/cnt[0]:.3f} ms/launch ({fl[0]/ms[0]/1e9:.0f} TF)", flush=True)
     del x, P; torch.cuda.empty_cache()
