@@ -153,6 +153,26 @@ __device__ __forceinline__ void gload16x2(f32x4& d0, f32x4& d1, const void* p) {
 }
 __device__ __forceinline__ void tie_regs(f32x4& x0, f32x4& x1) { asm volatile("" : "+v"(x0), "+v"(x1)::"memory"); }
 
+// 4 x 4 transpose across the four lanes of a quad: in, lane q holds x_k = M[q][k]; out, lane q holds x_k = M[k][q].
+// Two butterfly stages (lane bit 0 with register pairs (0,1), (2,3); lane bit 1 with pairs (0,2), (1,3)); each moves one register
+// per pair through a DPP quad permute and selects by lane parity.
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, float& x3, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float t;
+  t = quad_perm<0xB1>(b0 ? x0 : x1);  // [1,0,3,2]
+  if (b0) x0 = t; else x1 = t;
+  t = quad_perm<0xB1>(b0 ? x2 : x3);
+  if (b0) x2 = t; else x3 = t;
+  t = quad_perm<0x4E>(b1 ? x0 : x2);  // [2,3,0,1]
+  if (b1) x0 = t; else x2 = t;
+  t = quad_perm<0x4E>(b1 ? x1 : x3);
+  if (b1) x1 = t; else x3 = t;
+}
+
 template <int... I, typename F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -590,7 +610,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     // ---- epilogue of the current tile.  Rows of a 32x32 accumulator tile held by this lane: 8g + 4h + k (g, k = 0..3);
     // the four k rows are four consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per
     // (i, g).  Loads are issued unconditionally on clamped addresses (batched ahead of the math); stores are predicated
-    // and fire-and-forget: they drain while the next tile's main loop runs.
+    // and fire-and-forget: they drain while the next tile's main loop runs (they are OLDER than every vector-memory operation
+    // the next tile counts, so their number does not enter the counted waits).
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       size_t pixb[4];
@@ -623,30 +644,47 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           for (int e = 0; e < 16; ++e) rv[e] = 0.f;
         }
         float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // rows 0-15 / 16-31 of this tile (two images when PPI == 16)
+        float v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int g = e >> 2;
-          const float v = acc[i][c][e] * inv_scale + bias + ev[g] + rv[e];
+          v[e] = acc[i][c][e] * inv_scale + bias + ev[g] + rv[e];
           acc[i][c][e] = 0.f;  // ready for the next tile
           if (okg[g]) {
+            if (e < 8) {
+              s0 += v[e];
+              q0 += v[e] * v[e];
+            } else {
+              s1 += v[e];
+              q1 += v[e] * v[e];
+            }
+          }
+        }
+        if (a.out_nchw || ks > 1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int g = e >> 2;
+            if (!okg[g]) continue;
             if (a.out_nchw) {
               if (co < a.cout_valid) {
                 const size_t pix = pixb[g] + (e & 3);
                 const size_t hw = (size_t)a.H * a.W;
-                a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v;
+                a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v[e];
               }
-            } else if (ks > 1) {
-              unsafeAtomicAdd(&a.out[(pixb[g] + (e & 3)) * a.Cout + co], v);  // global_atomic_add_f32, no return
             } else {
-              a.out[(pixb[g] + (e & 3)) * a.Cout + co] = v;
+              unsafeAtomicAdd(&a.out[(pixb[g] + (e & 3)) * a.Cout + co], v[e]);  // global_atomic_add_f32, no return
             }
-            if (e < 8) {
-              s0 += v;
-              q0 += v * v;
-            } else {
-              s1 += v;
-              q1 += v * v;
-            }
+          }
+        } else {
+          // NHWC store, 16 bytes per lane: the accumulator layout gives a lane ONE channel of four consecutive pixels per row
+          // group g; a 4 x 4 transpose inside every quad of lanes (two DPP butterfly stages) turns that into FOUR channels of one
+          // pixel, so a wave writes a 32-channel row group with 4 global_store_dwordx4 instead of 16 global_store_dword -- the store
+          // tail was issue-bound (64 store instructions per wave and tile; stamp timeline: 19 % of a K = 1152 tile).
+          const int cq = cur.co0 + (wn * NT + c) * 32 + (r & ~3);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], r);
+            if (okg[g]) *reinterpret_cast<float4*>(&a.out[(pixb[g] + (r & 3)) * a.Cout + cq]) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
           }
         }
         if (st) {
