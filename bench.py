@@ -2,7 +2,9 @@
 """Headline benchmark: U-Net denoise steps/sec of DRMNet's reverse process on synthetic 3x128x256 refmaps.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+    N > 1 works both ways: launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or as the plain command above, in
+    which case this process spawns the N ranks itself as fresh child processes BEFORE it touches the GPU and relays rank 0's line.
 
 One "step" = one pass of the hot path over one batch: a full DRMNet reverse step for `--batch` refmaps per GPU
 (RefNet forward -> BRDF schedule -> z-embedding MLP -> IllNet forward -> fused state update, models/drmnet.py:809-825 of
@@ -52,6 +54,7 @@ def parse():
                          "accumulate: passes the SAME parity tolerances as fp32 (tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-strict-fp32", action="store_true", help="skip the short exact-fp32 pass that follows the headline measurement")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the batch-1 parity forward passes (keeps a rocprofv3 trace of this command to the timed workload's launches)")
     return ap.parse_args()
 
@@ -136,6 +139,7 @@ def make_step(args, model, dev):
             state["i"] += 1
 
         gf = GFLOP["illnet"].get(key, 0) + GFLOP["refnet"].get(key, 0)
+        step.state = Lr_k  # the tensor every step updates in place: main() checks it stays finite
         return step, gf, "DRMNet reverse step = RefNet + z-MLP + IllNet + update (all rows active)"
     if args.workload in ("illnet", "refnet", "obsnet"):
         unet = {"illnet": lambda: model.illnet_model.diffusion_model, "refnet": lambda: model.refnet_model.diffusion_model,
@@ -233,6 +237,106 @@ def cpu_baseline(args):
     return {"value": round(n / dt, 4), "unit": "U-Net denoise steps/sec", "cores": threads, "kind": "port",
             "sample": f"{n} DRMNet reverse steps (RefNet+IllNet, fp32) of 1 refmap 3x{H}x{W}, oracle/ on host CPU, {dt:.1f}s"}
 
+DOMINANT_VARIANT = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3>"
+
+
+def kernel_source_hash() -> str:
+    import hashlib
+
+    with open(os.path.join(ROOT, "drmnet_amd", "csrc", "conv_split2.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def imported_traffic(applicable: bool) -> dict:
+    import glob
+
+    out = {"traffic": None}
+    if not applicable:
+        return out
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+            k = prof["kernels"][DOMINANT_VARIANT]
+        except (OSError, KeyError, ValueError):
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if prof.get("conv_split2_sha16") != kernel_source_hash():
+            out["traffic_note"] = f"{rel} was measured on a different conv_split2.hip (sha {prof.get('conv_split2_sha16')}): not imported"
+            return out
+        out["traffic"] = k["hbm_bytes_per_launch_corrected"]
+        out["traffic_source"] = f"imported from {rel} (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch of {DOMINANT_VARIANT}; same kernel source, sha {prof['conv_split2_sha16']})"
+        return out
+    return out
+
+
+def rank_aggregate(dt_local: float, units_local: float, dist=None, device=None):
+    """The contract's aggregation: time = MAX over ranks of the barrier-bracketed loop, work = SUM over ranks of the units each
+    rank processed; value = work / time.  `dist` = an initialised torch.distributed module (nccl on GPUs, gloo in the CPU test)
+    or None for a single process.  Returns (time_s, total_units)."""
+    if dist is None:
+        return dt_local, units_local
+    t = torch.tensor([dt_local], dtype=torch.float64, device=device)
+    u = torch.tensor([units_local], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start one fresh child process per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torch.distributed.run would), wait for them, return the worst exit code.  Runs before this
+    process has made any HIP call (torch.cuda.device_count() does not initialise the runtime): a process that has touched the GPU
+    must never be replaced or forked on this pool.  Rank 0's stdout (the JSON line) is inherited; other ranks' stdout is dropped."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+def strict_fp32_pass(args, model, dev, L, _lib):
+    """The same workload in exact-fp32 arithmetic (v_mfma_f32_32x32x2_f32), a short untimed-region pass run AFTER the headline
+    measurement so the driver's record carries both numbers (the headline is the fp32-accurate split mode)."""
+    model.set_precision("fp32")
+    step, gflop, _ = make_step(args, model, dev)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    L.drm_profile_reset()
+    L.drm_profile_enable(2)
+    n = 4
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    L.drm_profile_enable(0)
+    K0 = 5
+    tm, tf, tb, tn = (C.c_double * K0)(), (C.c_double * K0)(), (C.c_double * K0)(), (C.c_int64 * K0)()
+    _lib.check(L.drm_profile_collect(tm, tf, tb, tn))
+    ach = tf[0] / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else None
+    return {"value": round(args.batch * n / dt, 3), "unit": "denoise steps/sec (samples x steps / s)", "steps": n, "ms_per_step": round(dt / n * 1e3, 3),
+            "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)",
+            "roofline": None if ach is None else {"bound": "mfma", "kernel": "conv_igemm_kernel<9,...>", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                                  "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(tm[0] / max(tn[0], 1), 4)}}
+
 
 def main():
     args = parse()
@@ -240,9 +344,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-            sys.exit(2)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            sys.exit(self_launch(args))  # no launcher: spawn the ranks ourselves (before any HIP call in this process)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: drmnet_amd has no CPU path", file=sys.stderr)
         sys.exit(2)
@@ -278,6 +383,12 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # non-finite operands would toggle fewer datapath bits (and raise the clock): the timed state must still be a number
+    state = getattr(step, "state", None)
+    state_finite = None if state is None else bool(torch.isfinite(state).all().item())
+    if state_finite is False:
+        print("bench.py: the sampler state went non-finite inside the timed region; the measurement is invalid", file=sys.stderr)
+        sys.exit(3)
     timed = None
     if profile:
         L.drm_profile_enable(0)
@@ -292,10 +403,7 @@ def main():
             step()
         barrier()
         L.drm_profile_enable(0)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, total_units = rank_aggregate(dt, float(args.batch * args.steps), dist, dev)
 
     roofline = None
     breakdown = None
@@ -332,21 +440,13 @@ def main():
                 # (tools/mfma_peak.hip, profiles/r01_mfma_power_limit.json): 1.43-1.67 PFLOP/s, not the 2.5 PFLOP/s of the data sheet
                 roofline["power_limited_f16_mfma_tflops_measured"] = [1430.0, 1670.0]
                 roofline["executed_frac_of_power_limited_peak"] = [round(3 * ach / 1670.0, 4), round(3 * ach / 1430.0, 4)]
-            # HBM traffic is a PMC quantity: it cannot be read from inside this process, so it is taken from the committed
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/), dominant variant, per launch
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                    pmc = json.load(f)["kernels"]
-                key = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3>"
-                if split and key in pmc and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256):
-                    roofline["traffic"] = pmc[key]["hbm_bytes_per_launch_corrected"]
-                    roofline["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch of " + key + ")"
-            except (OSError, KeyError, ValueError):
-                pass
+            # HBM traffic is a PMC quantity: it cannot be read from inside this process.  It is IMPORTED from the committed rocprofv3
+            # --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/prof_round.sh -> profiles/rNN_pmc_hbm_traffic.json), per
+            # launch of the dominant variant -- and only when that profile was taken on the kernel source this build was made from.
+            roofline.update(imported_traffic(split and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256)))
 
     if rank == 0:
-        total_steps = args.batch * world * args.steps
-        value = total_steps / dt
+        value = total_units / dt
         out = {
             "metric": "full-chain samples/sec" if args.workload == "estimate_chain" else "U-Net denoise steps/sec on 3x128x256 refmaps",
             "value": round(value, 3),
@@ -368,8 +468,11 @@ def main():
             "kernel_breakdown": breakdown,
             "kernel_breakdown_note": "conv3x3 row and the roofline object: HIP events inside the timed region; other rows: a second, untimed pass of the same steps with every kernel family instrumented",
         }
+        out["state_finite"] = state_finite
         if args.workload == "drmnet_step" and not args.no_parity_check:
             out["parity_check"] = parity_check(model, dev, args.precision)
+        if world == 1 and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_strict_fp32:
+            out["strict_fp32"] = strict_fp32_pass(args, model, dev, L, _lib)
         if world == 1 and not args.no_cpu_baseline and args.workload == "drmnet_step":
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

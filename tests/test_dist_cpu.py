@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from drmnet_amd.dist import gather_results, sample_sharded, shard_rows
+from drmnet_amd.dist import gather_results, sample_sharded, shard_indices, shard_rows
 
 
 def test_shard_rows_partition():
@@ -40,6 +40,14 @@ def _fake_sampler(x):
     return Lr0, zK, K
 
 
+def test_strided_sharding_deals_rows_round_robin():
+    for n in (0, 1, 7, 32):
+        for w in (1, 2, 3, 8):
+            owned = [shard_indices(n, w, r, strided=True) for r in range(w)]
+            assert sorted(torch.cat(owned).tolist()) == list(range(n))
+            assert all(ix.tolist() == list(range(r, n, w)) for r, ix in enumerate(owned))
+
+
 def _worker(rank, world, port, n):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -63,6 +71,17 @@ def _worker(rank, world, port, n):
         mine = torch.full((b - a, 2), float(rank))
         (full,) = gather_results([mine], n)
         assert full.shape[0] == n and torch.equal(full[a:b], mine)
+        # strided dealing (the early-exit layout): same results, rows rank, rank + world, ...
+        calls.clear()
+        got = sample_sharded(fn, [x], strided=True)
+        assert calls == [len(range(rank, n, world))]
+        for g_, want in zip(got, ref):
+            assert torch.equal(g_, want)
+        # bench.py's own aggregation: the job's time is the SLOWEST rank's, its work the SUM over ranks
+        import bench
+
+        t, units = bench.rank_aggregate(0.5 + 0.25 * rank, 32.0 * 10 * (rank + 1), dist, None)
+        assert t == 0.5 + 0.25 * (world - 1) and units == 32.0 * 10 * sum(range(1, world + 1))
     finally:
         dist.destroy_process_group()
 
@@ -71,3 +90,16 @@ def _worker(rank, world, port, n):
 def test_two_rank_gloo_sharded_sampling(n):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, n), nprocs=2, join=True)
+
+
+def test_bench_aggregate_single_process_and_self_launch_refusal(capsys):
+    """Single process: aggregation is the identity.  `--gpus 2` with no launcher on a box without two GPUs must refuse loudly
+    (exit code 2) before spawning anything -- the check runs on torch.cuda.device_count(), which does not initialise the GPU."""
+    import argparse
+
+    import bench
+
+    assert bench.rank_aggregate(0.25, 320.0) == (0.25, 320.0)
+    if torch.cuda.device_count() < 2:
+        assert bench.self_launch(argparse.Namespace(gpus=2)) == 2
+        assert "GPU(s) are visible" in capsys.readouterr().err

@@ -2,8 +2,8 @@
 # Regenerates the round's judged profile artifacts on the GPU box (run through gpurun, then copy gpurun_out/prof_round/*
 # into profiles/):  kernel stats of the default bench command, the bench line measured without the profiler, and the two
 # PMC passes (FETCH_SIZE, WRITE_SIZE) for the HBM traffic of the dominant kernels.
-#   usage: tools/prof_round.sh <tag>        e.g. tools/prof_round.sh r01
-tag=${1:-r01}
+#   usage: tools/prof_round.sh <tag>        e.g. tools/prof_round.sh r02
+tag=${1:-r02}
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/prof_round"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -36,7 +36,9 @@ def counter(sub, name):
         acc[k][0] += v; acc[k][1].add(disp)
     return {k: (s, len(d)) for k, (s, d) in acc.items()}
 fe, wr = counter('pmc_fetch', 'FETCH_SIZE'), counter('pmc_write', 'WRITE_SIZE')
-res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile (two separate passes; tools/prof_round.sh)",
+import hashlib
+res = {"conv_split2_sha16": hashlib.sha256(open('drmnet_amd/csrc/conv_split2.hip', 'rb').read()).hexdigest()[:16],
+       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile (two separate passes; tools/prof_round.sh)",
        "units": "FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of wide (16 B/lane) streaming reads (MI355X_MICROARCH.md HBM section): corrected = 2 x FETCH_SIZE",
        "kernels": {}}
 for k, (s, n) in sorted(fe.items(), key=lambda kv: -kv[1][0])[:12]:
