@@ -200,14 +200,21 @@ int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, 
       float* resn = ar.alloc<float>(N * hw * coutp);
       float* gp = ar.alloc<float>(cinp);
       float* bpn = ar.alloc<float>(cinp);
+      ConvArgs a;
       if (ar.dry) {
         xa.mom_valid = false;
-        return ensure_moments(c, xa);
+        DRM_TRY(ensure_moments(c, xa));
+        if (!gamma) DRM_TRY(raw_input_guard(c, a, &xa, 0, cinp, nullptr, nullptr, cinp));
+        return DRM_OK;
       }
       DRM_TRY(launch_pack_input(x, nullptr, nullptr, xa.p, N, H, W, Cin, 0, cinp, s));
       DRM_TRY(pack_for_ops(w, wp, wb, scratch, Cout, Cin, taps, coutp, cinp, s));
       if (b) DRM_HIP_CHECK(hipMemcpyAsync(bp, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
-      ConvArgs a;
+      if (!gamma) {
+        xa.mom_valid = false;
+        DRM_TRY(ensure_moments(c, xa));
+        DRM_TRY(raw_input_guard(c, a, &xa, 0, cinp, nullptr, nullptr, cinp));
+      }
       if (gamma) {
         DRM_HIP_CHECK(hipMemcpyAsync(gp, gamma, Cin * sizeof(float), hipMemcpyDeviceToDevice, s));
         DRM_HIP_CHECK(hipMemcpyAsync(bpn, beta, Cin * sizeof(float), hipMemcpyDeviceToDevice, s));

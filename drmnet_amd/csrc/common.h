@@ -85,6 +85,7 @@ struct ConvArgs {
 #endif
   double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)
   const float* w_inv_scale = nullptr;  // split-precision path: device scalar 2^-k undoing the weight pre-scaling
+  const float* in_inv = nullptr;       // split-precision path: [N] per-image 2^-k undoing the input staging factor (launch_act_pow2_scale)
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 // split-precision (fp16 hi/lo x 3 MFMA, fp32-accurate) variant; a.w = pre-split weights (conv_split.hip)
@@ -105,6 +106,9 @@ int launch_chan_moments(const float* x, int N, int HW, int C, double* partial /*
 int chan_moments_splits(int HW, int C);
 // combine moments of up to two concatenated sources into per-(n,c) scale/shift (32 groups, eps 1e-5)
 // inv0 / inv1: factor turning a table into per-pixel means (1 for tables of means, 1/(H*W) for tables of raw sums)
+// per-image power-of-two staging factor for un-normalised inputs of the split-precision convs (gn.hip)
+int launch_act_pow2_scale(const double2* mom0, int C0, int lo0, int hi0, double cnt0, const double2* mom1, int C1, double cnt1,
+                          const unsigned* absmax_bits, int Ctab, int N, float* scale, float* shift, float* inv, hipStream_t s);
 int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* mom1, int C1, double inv1, const float* gamma,
                        const float* beta, int N, float* scale, float* shift, hipStream_t s);
 
@@ -126,7 +130,9 @@ int launch_mirmap2envmap(const float* mir, const float* basis, float* out, int B
 int launch_hdr2ldr(const float* x, const unsigned char* mask, int HW, float alpha, float gamma, float* out, hipStream_t s);
 
 // misc kernels (misc.hip)
-int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s);
+// absmax_bits (optional): [N] words, zeroed by the caller; receives max |element| per packed image as fp32 bits
+int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s,
+                      unsigned* absmax_bits = nullptr);
 int launch_avgpool2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
 int launch_linear(const float* in, const float* w, const float* b, float* out, int N, int I, int O, int silu_in, int silu_out, hipStream_t s);
 int launch_timestep_embedding(const int64_t* t, const float* tf, float* out, int N, int dim, hipStream_t s);

@@ -633,9 +633,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         const int co = cur.co0 + col;
         const bool first = split == 0;
         const float bias = (a.bias && first) ? a.bias[co] : 0.f;
-        float rv[16], ev[4];
+        float rv[16], ev[4], sv[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) ev[g] = (a.emb && first) ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
+        for (int g = 0; g < 4; ++g) {
+          ev[g] = (a.emb && first) ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
+          sv[g] = a.in_inv ? inv_scale * a.in_inv[nimg[g]] : inv_scale;  // weight and (per image) input staging factors, both 2^-k
+        }
         if (a.res && first && !(ks > 1 && a.res == a.out)) {  // split-K on an in-place residual: `out` already holds it
 #pragma unroll
           for (int e = 0; e < 16; ++e) rv[e] = a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co];
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int g = e >> 2;
-          v[e] = acc[i][c][e] * inv_scale + bias + ev[g] + rv[e];
+          v[e] = acc[i][c][e] * sv[g] + bias + ev[g] + rv[e];
           acc[i][c][e] = 0.f;  // ready for the next tile
           if (okg[g]) {
             if (e < 8) {

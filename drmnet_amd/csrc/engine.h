@@ -147,6 +147,8 @@ int run_attention(Ctx& c, const float* wbuf, const AttnLayer& a, Act& x, Act& ou
 // dispatches to the fp32 or the split-precision conv kernel; scale_off = the conv's pre-scaling slot in wbuf
 // `stats_for` (optional): the activation this conv completes -- its GroupNorm statistics are then accumulated in the epilogue
 int run_conv(Ctx& c, ConvArgs& a, const float* wbuf, size_t scale_off, Act* stats_for = nullptr);
+// split-precision range guard for an un-normalised conv input (see engine.hip)
+int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab);
 // ensure_moments on both sources + gn_finalize into (scale, shift)
 int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift);
 

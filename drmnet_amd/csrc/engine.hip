@@ -303,6 +303,27 @@ int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_
   return launch_conv(a, c.s);
 }
 
+// Split-precision convs on an UN-normalised input (skip_connection, proj_out, stem): stage it through a per-image power of two
+// derived from a rigorous bound of max |x| (gn.hip act_pow2_scale_kernel) so nothing saturates or underflows fp16; the factor rides
+// on the (scale, shift) tables the staging path applies anyway and is undone per image in the epilogue.  Bound source: the
+// per-channel sum-of-squares tables of x0 (channels [lo0, hi0)) and x1, or an absmax word per image.  No-op in fp32 mode.
+int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab) {
+  if (!c.split()) return DRM_OK;
+  float* sc = c.ar->alloc<float>((size_t)c.N * Ctab);
+  float* sh = c.ar->alloc<float>((size_t)c.N * Ctab);
+  float* inv = c.ar->alloc<float>((size_t)c.N);
+  if (x0) DRM_TRY(ensure_moments(c, *x0));
+  if (x1) DRM_TRY(ensure_moments(c, *x1));
+  if (c.dry()) return DRM_OK;
+  auto cnt = [](const Act& t) { return t.mom_sums ? 0.0 : (double)(t.H >> t.up) * (t.W >> t.up); };
+  DRM_TRY(launch_act_pow2_scale(x0 ? x0->mom : nullptr, x0 ? x0->C : 0, lo0, hi0, x0 ? cnt(*x0) : 0.0, x1 ? x1->mom : nullptr, x1 ? x1->C : 0,
+                                x1 ? cnt(*x1) : 0.0, absmax_bits, Ctab, c.N, sc, sh, inv, c.s));
+  a.gn_scale = sc;
+  a.gn_shift = sh;
+  a.in_inv = inv;
+  return DRM_OK;
+}
+
 int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift) {
   DRM_TRY(ensure_moments(c, x0));
   if (x1) DRM_TRY(ensure_moments(c, *x1));
@@ -335,10 +356,11 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
     DRM_TRY(run_conv(c, a, Wb, r.c1_s, &h1));
   }
   DRM_TRY(gn_params(c, h1, nullptr, Wb + r.n2_w, Wb + r.n2_b, sc2, sh2));
+  ConvArgs k;  // skip_connection: 1x1 conv on the raw (un-normalised) block input
+  if (r.has_skip) DRM_TRY(raw_input_guard(c, k, &x0, 0, C0, x1, nullptr, r.cin));
   if (!c.dry()) {
     const float* res = x0.p;
     if (r.has_skip) {
-      ConvArgs k;
       k.src0 = x0.p; k.src1 = x1 ? x1->p : nullptr; k.C0 = C0; k.C1 = C1; k.up0 = x0.up;
       k.N = c.N; k.H = H; k.W = W;
       k.w = Wb + r.sk_w; k.bias = Wb + r.sk_b; k.taps = 1; k.Cout = r.cout;
@@ -364,17 +386,24 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   float* sc = c.ar->alloc<float>((size_t)c.N * C);
   float* sh = c.ar->alloc<float>((size_t)c.N * C);
   DRM_TRY(gn_params(c, x, nullptr, Wb + l.n_w, Wb + l.n_b, sc, sh));
-  float* qkv = c.ar->alloc<float>((size_t)c.N * T * 3 * C);
+  Act qkv_act = new_act(c, 3 * C, H, W);  // its per-channel sums (fused into the qkv conv's epilogue) bound |v| >= |attention output|
+  float* qkv = qkv_act.p;
   float* scores = c.ar->alloc<float>((size_t)c.N * T * T);
   float* att = c.ar->alloc<float>((size_t)c.N * T * C);
+  ConvArgs p;  // proj_out: 1x1 conv on the raw attention output, a convex combination of v rows: max |att| <= max |v|
   if (!c.dry()) {
     ConvArgs a;
     a.src0 = x.p; a.C0 = C; a.N = c.N; a.H = H; a.W = W;
     a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
     a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.taps = 1; a.Cout = 3 * C; a.out = qkv;
-    DRM_TRY(run_conv(c, a, Wb, l.qkv_s));
+    DRM_TRY(run_conv(c, a, Wb, l.qkv_s, &qkv_act));
     DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split() ? c.terms() : 0));
-    ConvArgs p;
+  } else {
+    qkv_act.mom_valid = true;  // sizing pass: the table is filled by the conv epilogue, no stand-alone moments launch
+    qkv_act.mom_sums = true;
+  }
+  DRM_TRY(raw_input_guard(c, p, &qkv_act, 2 * C, 3 * C, nullptr, nullptr, C));
+  if (!c.dry()) {
     p.src0 = att; p.C0 = C; p.N = c.N; p.H = H; p.W = W;
     p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.taps = 1; p.Cout = C; p.res = x.p; p.out = out.p;
     DRM_TRY(run_conv(c, p, Wb, l.proj_s, &out));
@@ -429,12 +458,15 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   } pool_scope{ar};
 
   Act xin = new_act(c, in_cp, H, W);
+  bool amax_zeroed = false;
+  unsigned* amax = reinterpret_cast<unsigned*>(c.ar->alloc_stats((size_t)N * sizeof(unsigned), &amax_zeroed));  // per-image max |input|
   float* temb = c.ar->alloc<float>((size_t)N * mc);
   float* e1 = c.ar->alloc<float>((size_t)N * emb_dim);
   float* emb = c.ar->alloc<float>((size_t)N * emb_dim);
   float* emb_all = c.ar->alloc<float>((size_t)N * emb_total);
   if (!c.dry()) {
-    DRM_TRY(launch_pack_input(x, cond, rows, xin.p, N, H, W, Cx, Cc, in_cp, s));
+    if (!amax_zeroed) DRM_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)N * sizeof(unsigned), s));
+    DRM_TRY(launch_pack_input(x, cond, rows, xin.p, N, H, W, Cx, Cc, in_cp, s, amax));
     const float* te = t_emb;
     if (!te) {
       DRM_TRY(launch_timestep_embedding(t, tf, temb, N, mc, s));
@@ -452,8 +484,9 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   };
   std::vector<Act*> hs;
   Act* h = make(mc, H, W);
+  ConvArgs a;  // stem conv: raw network input
+  DRM_TRY(raw_input_guard(c, a, nullptr, 0, 0, nullptr, amax, in_cp));
   if (!c.dry()) {
-    ConvArgs a;
     a.src0 = xin.p; a.C0 = in_cp; a.N = N; a.H = H; a.W = W;
     a.w = Wb + stem_w; a.bias = Wb + stem_b; a.taps = 9; a.Cout = mc; a.out = h->p; a.cin_real = desc.in_channels;
     DRM_TRY(run_conv(c, a, Wb, stem_s, h));

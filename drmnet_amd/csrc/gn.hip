@@ -126,6 +126,60 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restr
   }
 }
 
+// Range guard of the split-precision path for UN-normalised conv inputs (ResBlock skip_connection, AttentionBlock proj_out, the
+// stem: openaimodel.py:241, :314, :534).  The fp16 hi/lo split keeps 22 bits only while the staged values sit inside fp16's
+// normal range, so such a tensor is staged through an exact power-of-two factor per image, undone in the epilogue:
+//   bound[n] = a rigorous upper bound of max |x| over image n  --  sqrt(max_c sum_pixels x^2), from the per-channel (sum, sum of
+//              squares) tables the GroupNorm fusion already keeps, or an explicit absmax word;
+//   2^k[n]   = the largest power of two with bound * 2^k <= 2^15  (no element can reach the fp16 limit 65504; a typical element,
+//              rms ~ bound / sqrt(H W), lands around 2^15 / sqrt(H W) >= 2^7.5: hi AND lo stay normal fp16 numbers).
+// Written as the (scale, shift) = (2^k, 0) table the staging path already applies (an exact multiply) plus inv[n] = 2^-k.
+// grid N, block 256.  cnt: pixels per table entry when the table holds means instead of raw sums (0 = raw sums).
+__global__ __launch_bounds__(256) void act_pow2_scale_kernel(const double2* __restrict__ mom0, int C0, int lo0, int hi0, double cnt0,
+                                                             const double2* __restrict__ mom1, int C1, double cnt1,
+                                                             const unsigned* __restrict__ absmax_bits, int Ctab, float* __restrict__ scale,
+                                                             float* __restrict__ shift, float* __restrict__ inv) {
+  __shared__ double red[4];
+  __shared__ float s_scale;
+  const int n = blockIdx.x, t = threadIdx.x;
+  double m = 0.0;
+  if (mom0)
+    for (int c = lo0 + t; c < hi0; c += 256) m = fmax(m, mom0[(size_t)n * C0 + c].y * (cnt0 > 0 ? cnt0 : 1.0));
+  if (mom1)
+    for (int c = t; c < C1; c += 256) m = fmax(m, mom1[(size_t)n * C1 + c].y * (cnt1 > 0 ? cnt1 : 1.0));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((t & 63) == 0) red[t >> 6] = m;
+  __syncthreads();
+  if (t == 0) {
+    double bound = sqrt(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
+    if (absmax_bits) bound = fmax(bound, (double)__uint_as_float(absmax_bits[n]));
+    int k = 0;
+    if (bound > 0.0 && bound < INFINITY) {
+      int e;
+      frexp(bound, &e);  // bound = f * 2^e, f in [0.5, 1)
+      k = 15 - e;        // bound * 2^k in [2^14, 2^15)
+      k = k > 90 ? 90 : (k < -90 ? -90 : k);  // the epilogue multiplies 2^-k by the weights' 2^-k' (|k'| <= 30) in fp32
+    }
+    s_scale = ldexpf(1.0f, k);
+    inv[n] = ldexpf(1.0f, -k);
+  }
+  __syncthreads();
+  const float sc = s_scale;
+  for (int c = t; c < Ctab; c += 256) {
+    scale[(size_t)n * Ctab + c] = sc;
+    shift[(size_t)n * Ctab + c] = 0.f;
+  }
+}
+
+int launch_act_pow2_scale(const double2* mom0, int C0, int lo0, int hi0, double cnt0, const double2* mom1, int C1, double cnt1,
+                          const unsigned* absmax_bits, int Ctab, int N, float* scale, float* shift, float* inv, hipStream_t s) {
+  DRM_REQUIRE((mom0 || absmax_bits) && scale && shift && inv && N > 0 && Ctab > 0, "act_pow2_scale: arguments");
+  hipLaunchKernelGGL(act_pow2_scale_kernel, dim3(N), dim3(256), 0, s, mom0, C0, lo0, hi0, cnt0, mom1, C1, cnt1, absmax_bits, Ctab, scale, shift, inv);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
 int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* mom1, int C1, double inv1, const float* gamma,
                        const float* beta, int N, float* scale, float* shift, hipStream_t s) {
   DRM_REQUIRE((C0 + C1) % 32 == 0, "GroupNorm32 needs channels % 32 == 0");

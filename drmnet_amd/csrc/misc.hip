@@ -14,15 +14,19 @@ __device__ __forceinline__ float silu_m(float v) { return v / (1.0f + __expf(-v)
 // ---------------------------------------------------------------------------------------------
 // One thread per (pixel, 4-channel quad): the NHWC writes are fully coalesced 16-byte stores; only the first
 // (Cx + Cc + 3) / 4 quads read anything.
-__global__ void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ cond, const int* __restrict__ idx,
-                                  float4* __restrict__ out, int N, int HW, int Cx, int Cc, int Q) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)N * HW * Q) return;
-  const int q = (int)(i % Q);
-  const long long pix = i / Q;
-  const int n = (int)(pix / HW), p = (int)(pix % HW);
+// grid (blocks over one image, N): a block never straddles two images, so the optional per-image absmax is one wave
+// reduction + one atomicMax per wave (non-negative floats order like their bit patterns).
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ cond, const int* __restrict__ idx,
+                                                          float4* __restrict__ out, int N, int HW, int Cx, int Cc, int Q,
+                                                          unsigned* __restrict__ absmax_bits) {
+  const int n = blockIdx.y;
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, quad) inside image n
   float v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (4 * q < Cx + Cc) {
+  const bool live = j < (long long)HW * Q;
+  const int q = (int)(j % Q);
+  const int p = (int)(j / Q);
+  const long long i = (long long)n * HW * Q + j;
+  if (live && 4 * q < Cx + Cc) {
     const int src = idx ? idx[n] : n;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -31,14 +35,22 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
       else if (c < Cx + Cc) v[k] = cond[((size_t)src * Cc + (c - Cx)) * HW + p];
     }
   }
-  out[i] = make_float4(v[0], v[1], v[2], v[3]);
+  if (live) out[i] = make_float4(v[0], v[1], v[2], v[3]);
+  if (absmax_bits) {
+    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if (!(m == m)) m = INFINITY;  // NaN input: no finite bound
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax_bits + n, __float_as_uint(m));
+  }
 }
 
-int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s) {
+int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s,
+                      unsigned* absmax_bits) {
   DRM_REQUIRE(CP % 4 == 0, "packed input channels must be a multiple of 4");
-  const long long total = (long long)N * H * W * (CP / 4);
-  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cond, idx, reinterpret_cast<float4*>(out), N,
-                     H * W, Cx, Cc, CP / 4);
+  const long long per_image = (long long)H * W * (CP / 4);
+  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((per_image + 255) / 256), (unsigned)N), dim3(256), 0, s, x, cond, idx,
+                     reinterpret_cast<float4*>(out), N, H * W, Cx, Cc, CP / 4, absmax_bits);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }

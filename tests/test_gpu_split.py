@@ -47,6 +47,13 @@ def split_ops():
         (2, 128, 128, 16, 16, 1, False, False, False, False, 300.0),   # large raw activations (residual stream), no norm
         (2, 128, 128, 16, 16, 3, False, False, False, False, 1e-3),    # tiny raw activations: lo halves in the fp16 subnormal range
         (2, 128, 128, 16, 16, 3, True, True, False, False, 1e4),       # weights scaled far from O(1): exercised by the 2^k pre-scaling
+        # range guard of the un-normalised inputs (skip_connection / proj_out / stem: openaimodel.py:241, :314, :534): beyond the
+        # fp16 limit 65504 and deep inside fp16's subnormal range -- staged through a per-image power of two, must stay fp32-accurate
+        (2, 128, 128, 16, 16, 1, False, False, False, True, 1e5),
+        (2, 128, 128, 16, 16, 1, False, False, False, False, 1e-6),
+        (3, 256, 128, 8, 16, 3, False, False, True, False, 1e5),
+        (2, 6, 128, 16, 32, 3, False, False, False, False, 1e-6),      # the stem's shape (Cin = 6)
+        (2, 128, 128, 16, 16, 1, False, False, False, False, 3e7),
     ],
 )
 def test_split_norm_act_conv(dev, split_ops, n, cin, cout, h, w, k, norm, silu, emb, res, scale):
@@ -120,6 +127,54 @@ def test_split_full_width_nets_vs_reference_golden(dev, name, cfg, kind):
     assert rel_l2(out32.cpu(), gd["out"]) < NET_TOL
     del m
     torch.cuda.empty_cache()
+
+
+def test_range_guard_is_per_image_and_reaches_the_blocks(dev, split_ops):
+    """One batch holding a 1e5-scale image, an O(1) image and a 1e-6-scale image: every row keeps fp32-level accuracy (the staging
+    factor is per image, gn.hip act_pow2_scale_kernel).  Then the two block-level users: a ResBlock whose raw input feeds the
+    1x1 skip_connection at 1e4 x the usual magnitude, and an AttentionBlock whose value rows (hence proj_out's input) are large."""
+    gen = g(4242)
+    x = torch.randn((3, 128, 16, 16), generator=gen) * torch.tensor([1e5, 1.0, 1e-6]).view(3, 1, 1, 1)
+    wt = torch.randn((128, 128, 1, 1), generator=gen) / math.sqrt(128)
+    b = torch.zeros(128)
+    ref = F.conv2d(x.double(), wt.double())
+    out = split_ops.norm_act_conv(x.to(dev), wt.to(dev), b.to(dev)).cpu()
+    for r in range(3):
+        e = rel_l2(out[r], ref[r])
+        print(f"per-image guard row {r}: {e:.2e}")
+        assert e < OP_TOL
+    # ResBlock with a skip_connection on a large raw input (fp64 reference through the oracle's functional form)
+    cin, cout, hw = 256, 128, 16
+    xb, emb = block_inputs(cin, cout, hw, hw, 2)
+    xb = xb * 1e4
+    P = synth.synth_state_dict(resblock_manifest(cin, cout), 31)
+    D = {k: v.double() for k, v in P.items()}
+    sil = lambda t: t * torch.sigmoid(t)
+    hh = F.conv2d(sil(F.group_norm(xb.double(), 32, D["in_layers.0.weight"], D["in_layers.0.bias"], 1e-5)), D["in_layers.2.weight"], D["in_layers.2.bias"], padding=1)
+    hh = hh + F.linear(sil(emb.double()), D["emb_layers.1.weight"], D["emb_layers.1.bias"])[:, :, None, None]
+    hh = F.conv2d(sil(F.group_norm(hh, 32, D["out_layers.0.weight"], D["out_layers.0.bias"], 1e-5)), D["out_layers.3.weight"], D["out_layers.3.bias"], padding=1)
+    want = F.conv2d(xb.double(), D["skip_connection.weight"], D["skip_connection.bias"]) + hh
+    got = split_ops.resblock([p.to(dev) for p in P.values()], xb.to(dev), emb.to(dev)).cpu()
+    e = rel_l2(got, want)
+    print(f"resblock, raw input x 1e4: {e:.2e}")
+    assert e < OP_TOL
+    # AttentionBlock with the value third of qkv blown up 3e4 x (|att| ~ 1e5 > 65504)
+    ch, h, w = 512, 16, 16
+    xa, _ = block_inputs(ch, ch, h, w, 2)
+    Pa = synth.synth_state_dict(attn_manifest(ch), 32)
+    Pa["qkv.weight"][2 * ch:] *= 3e4
+    Pa["qkv.bias"][2 * ch:] *= 3e4
+    Pa["proj_out.weight"] *= 1e-4
+    A = {k: v.double() for k, v in Pa.items()}
+    xf = xa.double().reshape(2, ch, h * w)
+    qkv = F.conv1d(F.group_norm(xf, 32, A["norm.weight"], A["norm.bias"], 1e-5), A["qkv.weight"], A["qkv.bias"])
+    q, k_, v_ = qkv.split(ch, dim=1)
+    pw = torch.softmax(torch.einsum("bct,bcs->bts", q, k_) / math.sqrt(ch), dim=-1)
+    want = (xf + F.conv1d(torch.einsum("bts,bcs->bct", pw, v_), A["proj_out.weight"], A["proj_out.bias"])).reshape(2, ch, h, w)
+    got = split_ops.attention_block([p.to(dev) for p in Pa.values()], xa.to(dev)).cpu()
+    e = rel_l2(got - xa, want - xa.double())  # the residual x is added exactly: compare the attention branch itself
+    print(f"attention, value rows x 3e4: {e:.2e}")
+    assert e < 1e-4
 
 
 F16_NET_TOL = 5e-3  # DRM_PREC_F16 is a reduced-precision mode (one fp16 MFMA per product); its tolerance is its own
