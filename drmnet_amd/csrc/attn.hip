@@ -6,6 +6,8 @@
 // with the [N][T][T] score matrix in a workspace.  Attention is <= 4 % (IllNet) / 9 % (ObsNet) of the FLOPs
 // (SURVEY.md 8a), so the fused flash-style kernel is a later-round item; the GroupNorm, qkv and proj_out
 // projections and the residual add run in conv.hip (taps = 1).
+#include <algorithm>
+
 #include "common.h"
 #include "profiler.h"
 
@@ -231,6 +233,226 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
   for (int i = lane; i < T; i += 64) p[i] *= inv;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Split-precision attention core on the fused 1x1 conv pipeline (conv_split2.hip): both batched GEMMs are 1x1 "convolutions" whose
+// weights differ per image --
+//     S[n] = q[n] . k[n]^T : pixels = queries, Cin = C, Cout = T keys,   weights = k[n]      (rows of k are already [key][channel])
+//     O[n] = P[n] . v[n]   : pixels = queries, Cin = T keys, Cout = C,   weights = v[n]^T
+// -- so k and v^T are packed once per forward into the kernel's pre-split LDS-DMA weight image (hi/lo fp16 planes), each image
+// scaled by its own power of two, and the persistent 256-pixel x 128-channel tiles, the LDS-DMA weight ring and the 16-byte
+// transposed epilogue stores are reused as they are.  q and the probabilities are staged like any un-normalised activation
+// (per-image 2^k for q from the qkv conv's fused statistics, a fixed 2^12 for the probabilities); alpha = C^-1/2 rides on the
+// epilogue factor.  Needs one image per pixel tile: T = H*W a multiple of 256 (the T >= 512 levels, where the FLOPs are).
+// ------------------------------------------------------------------------------------------------------------------------------
+
+// per image: power-of-two factors of q, k, v from the per-channel sums of squares of the qkv tensor (bound * 2^k in [2^14, 2^15))
+// and everything the two conv launches read: tables [N][C] (2^kq), [N][T] (2^12), zeros, and the epilogue / weight factors
+__global__ __launch_bounds__(256) void attn_scales_kernel(const double2* __restrict__ mom, int C, int T, float alpha, float* __restrict__ q_tab,
+                                                          float* __restrict__ p_tab, float* __restrict__ zero_tab, float* __restrict__ qk_inv,
+                                                          float* __restrict__ k_scale, float* __restrict__ k_inv, float* __restrict__ pv_inv,
+                                                          float* __restrict__ v_scale, float* __restrict__ v_inv, float* __restrict__ o_tab) {
+  __shared__ double red[3][4];
+  __shared__ float s_q, s_v;
+  const int n = blockIdx.x, t = threadIdx.x;
+  double m[3] = {0.0, 0.0, 0.0};
+  for (int c = t; c < 3 * C; c += 256) m[c / C] = fmax(m[c / C], mom[(size_t)n * 3 * C + c].y);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m[j] = fmax(m[j], __shfl_xor(m[j], o));
+    if ((t & 63) == 0) red[j][t >> 6] = m[j];
+  }
+  __syncthreads();
+  if (t == 0) {
+    float sc[3], iv[3];
+    for (int j = 0; j < 3; ++j) {
+      const double bound = sqrt(fmax(fmax(red[j][0], red[j][1]), fmax(red[j][2], red[j][3])));
+      int k = 0;
+      if (bound > 0.0 && bound < INFINITY) {
+        int e;
+        frexp(bound, &e);
+        k = 15 - e;
+        k = k > 40 ? 40 : (k < -40 ? -40 : k);
+      }
+      sc[j] = ldexpf(1.0f, k);
+      iv[j] = ldexpf(1.0f, -k);
+    }
+    s_q = sc[0];
+    s_v = sc[2];
+    qk_inv[n] = alpha * iv[0];
+    k_scale[n] = sc[1];
+    k_inv[n] = iv[1];
+    pv_inv[n] = 1.0f / 4096.0f;
+    v_scale[n] = sc[2];
+    v_inv[n] = iv[2];
+  }
+  __syncthreads();
+  const float sq = s_q, sv = s_v;
+  for (int c = t; c < C; c += 256) {
+    q_tab[(size_t)n * C + c] = sq;
+    o_tab[(size_t)n * C + c] = sv;  // the attention output is a convex combination of v rows: the same bound guards proj_out's input
+  }
+  for (int c = t; c < T; c += 256) p_tab[(size_t)n * T + c] = 4096.0f;  // probabilities <= 1: 2^12 keeps the small ones normal in fp16
+  const int Z = C > T ? C : T;
+  for (int c = t; c < Z; c += 256) zero_tab[(size_t)n * Z + c] = 0.f;
+}
+
+// One image's GEMM "weights" W[co][ci] * scale[n] -> the pre-split LDS image of conv_split.hip ([chunk][hi|lo][slab s][lane half]
+// [Cout][8 halfs], taps = 1).  A thread produces one 16-byte (hi) + one 16-byte (lo) entry = 8 consecutive ci of one co.
+//   ROWS = true : W[co][ci] = src[n][co * ld + ci]  (k: rows are keys, ci = channels contiguous): the four octets of a 32-channel
+//                 chunk sit on four adjacent lanes, so a wave reads 16 whole 128-byte lines;
+//   ROWS = false: W[co][ci] = src[n][ci * ld + co]  (v^T: co = channel contiguous, ci = key): adjacent lanes take adjacent channels,
+//                 each of the 8 loads of a thread is a coalesced 256-byte row segment.
+// grid (blocks, N), block 256.
+template <bool ROWS>
+__global__ __launch_bounds__(256) void pack_attn_weight_kernel(const float* __restrict__ src, long long img_stride, int ld,
+                                                               const float* __restrict__ scale, float4* __restrict__ dst, int Cout, int Cin) {
+  const int n = blockIdx.y;
+  const float sc = scale[n];
+  const float* sp = src + (size_t)n * img_stride;
+  float4* dp = dst + (size_t)n * ((size_t)Cout * Cin / 4);  // hi + lo fp16 = 4 bytes per weight
+  const size_t units = (size_t)Cout * (Cin / 8);           // (co, octet of ci)
+  for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+    int co, oct_all;
+    if (ROWS) {
+      oct_all = (int)(u % 4) + 4 * (int)(u / ((size_t)4 * Cout));  // lanes: 4 octets of a chunk, then co
+      co = (int)((u / 4) % Cout);
+    } else {
+      co = (int)(u % Cout);
+      oct_all = (int)(u / Cout);
+    }
+    const int q = oct_all >> 2, seg = oct_all & 3;  // seg = slab * 2 + lane half
+    const int ci0 = 8 * oct_all;
+    float v[8];
+    if (ROWS) {
+      const float4* p4 = reinterpret_cast<const float4*>(sp + (size_t)co * ld + ci0);
+      const float4 x = p4[0], y = p4[1];
+      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sp[(size_t)(ci0 + j) * ld + co];
+    }
+    AF4H8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float c = __builtin_amdgcn_fmed3f(v[j] * sc, -65504.0f, 65504.0f);
+      const _Float16 hh = (_Float16)c;
+      hi.h8[j] = hh;
+      lo.h8[j] = (_Float16)(c - (float)hh);
+    }
+    dp[((size_t)q * 8 + seg) * Cout + co] = hi.f4;
+    dp[((size_t)q * 8 + 4 + seg) * Cout + co] = lo.f4;
+  }
+}
+
+// One-pass row softmax for rows of T = 256 * Q floats (Q <= 8): a wave keeps its row in registers (16 bytes per lane and load),
+// so the scores are read once and written once (the generic kernel above makes three passes over them).
+template <int Q>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* __restrict__ S, long long rows) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float4* p = reinterpret_cast<float4*>(S + row * (256ll * Q));
+  float4 v[Q];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    v[j] = p[j * 64 + lane];
+    m = fmaxf(m, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    v[j].x = expf(v[j].x - m); v[j].y = expf(v[j].y - m); v[j].z = expf(v[j].z - m); v[j].w = expf(v[j].w - m);
+    sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int j = 0; j < Q; ++j) p[j * 64 + lane] = make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
+}
+
+static int launch_softmax_rows(float* S, long long rows, int T, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (T % 256 == 0 && T / 256 <= 8) {
+    switch (T / 256) {
+      case 1: hipLaunchKernelGGL(softmax_rows_reg_kernel<1>, grid, block, 0, s, S, rows); break;
+      case 2: hipLaunchKernelGGL(softmax_rows_reg_kernel<2>, grid, block, 0, s, S, rows); break;
+      case 3: hipLaunchKernelGGL(softmax_rows_reg_kernel<3>, grid, block, 0, s, S, rows); break;
+      case 4: hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, grid, block, 0, s, S, rows); break;
+      case 5: hipLaunchKernelGGL(softmax_rows_reg_kernel<5>, grid, block, 0, s, S, rows); break;
+      case 6: hipLaunchKernelGGL(softmax_rows_reg_kernel<6>, grid, block, 0, s, S, rows); break;
+      case 7: hipLaunchKernelGGL(softmax_rows_reg_kernel<7>, grid, block, 0, s, S, rows); break;
+      default: hipLaunchKernelGGL(softmax_rows_reg_kernel<8>, grid, block, 0, s, S, rows); break;
+    }
+  } else {
+    hipLaunchKernelGGL(softmax_rows_kernel, grid, block, 0, s, S, rows, T);
+  }
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
+size_t attention_conv_workspace_floats(int N, int T, int C) {
+  const size_t Z = (size_t)(C > T ? C : T);
+  return 2 * (size_t)N * T * C + (size_t)N * (2 * C + T + Z) + 6 * (size_t)N + 64;
+}
+bool attention_conv_applicable(int T, int C, int H, int W, int terms) {
+  return terms != 0 && T % 256 == 0 && C % 128 == 0 && T % 128 == 0 && H % 16 == 0 && W % 16 == 0;
+}
+
+int launch_conv_split(const ConvArgs& a, hipStream_t s);
+
+// qkv [N][T][3C] (+ its fused per-channel statistics), scores workspace [N][T][T], out [N][T][C], ws: attention_conv_workspace_floats
+// proj_guard (optional): receives the (scale, shift, inverse) tables that guard proj_out's read of `out`
+int launch_attention_conv(const float* qkv, const double2* qkv_mom, float* scores, float* out, float* ws, int N, int H, int W, int C, int terms,
+                          hipStream_t s, ConvArgs* proj_guard) {
+  const int T = H * W;
+  DRM_REQUIRE(attention_conv_applicable(T, C, H, W, terms) && qkv_mom, "attention on the conv pipeline: shape");
+  const size_t Z = (size_t)(C > T ? C : T);
+  float* wk = ws;                           // [N] packed k:   Cout = T, Cin = C
+  float* wv = wk + (size_t)N * T * C;       // [N] packed v^T: Cout = C, Cin = T
+  float* q_tab = wv + (size_t)N * T * C;    // [N][C]
+  float* p_tab = q_tab + (size_t)N * C;     // [N][T]
+  float* zero_tab = p_tab + (size_t)N * T;  // [N][max(C, T)]
+  float* o_tab = zero_tab + (size_t)N * Z;  // [N][C]
+  float* vec = o_tab + (size_t)N * C;       // 6 x [N]
+  float *qk_inv = vec, *k_scale = vec + N, *k_inv = vec + 2 * N, *pv_inv = vec + 3 * N, *v_scale = vec + 4 * N, *v_inv = vec + 5 * N;
+  const float alpha = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, applied once to the dot product
+  prof_tag(N, T, 1, C, C);
+  ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C + 4.0 * T * T), s);  // one scope for the whole core
+  hipLaunchKernelGGL(attn_scales_kernel, dim3(N), dim3(256), 0, s, qkv_mom, C, T, alpha, q_tab, p_tab, zero_tab, qk_inv, k_scale, k_inv, pv_inv,
+                     v_scale, v_inv, o_tab);
+  DRM_HIP_CHECK(hipGetLastError());
+  if (proj_guard) {
+    proj_guard->gn_scale = o_tab;
+    proj_guard->gn_shift = zero_tab;
+    proj_guard->in_inv = v_inv;
+  }
+  const unsigned pb = (unsigned)std::min<size_t>(((size_t)T * C / 8 + 255) / 256, 4096);
+  hipLaunchKernelGGL(pack_attn_weight_kernel<true>, dim3(pb, N), dim3(256), 0, s, qkv + C, (long long)T * 3 * C, 3 * C, k_scale,
+                     reinterpret_cast<float4*>(wk), T, C);
+  DRM_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(pack_attn_weight_kernel<false>, dim3(pb, N), dim3(256), 0, s, qkv + 2 * C, (long long)T * 3 * C, 3 * C, v_scale,
+                     reinterpret_cast<float4*>(wv), C, T);
+  DRM_HIP_CHECK(hipGetLastError());
+  ConvArgs a;  // S = alpha q k^T
+  a.src0 = qkv; a.C0 = C; a.ld0 = 3 * C; a.N = N; a.H = H; a.W = W;
+  a.gn_scale = q_tab; a.gn_shift = zero_tab; a.silu = 0;
+  a.w = wk; a.w_img_stride_f4 = (long long)T * C / 4; a.w_inv_img = k_inv; a.in_inv = qk_inv;
+  a.taps = 1; a.Cout = T; a.out = scores; a.terms = terms; a.prof_kind = PROF_KINDS;  // (inside the scope above)
+  DRM_TRY(launch_conv_split(a, s));
+  DRM_TRY(launch_softmax_rows(scores, (long long)N * T, T, s));
+  ConvArgs b;  // O = P v
+  b.src0 = scores; b.C0 = T; b.N = N; b.H = H; b.W = W;
+  b.gn_scale = p_tab; b.gn_shift = zero_tab; b.silu = 0;
+  b.w = wv; b.w_img_stride_f4 = (long long)T * C / 4; b.w_inv_img = v_inv; b.in_inv = pv_inv;
+  b.taps = 1; b.Cout = C; b.out = out; b.terms = terms; b.prof_kind = PROF_KINDS;
+  return launch_conv_split(b, s);
+}
+
 int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms) {
   bool split = terms != 0;
   DRM_REQUIRE(C % 4 == 0 && T > 0 && N > 0, "attention shape");
@@ -249,9 +471,7 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
     hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
                        (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha);
   DRM_HIP_CHECK(hipGetLastError());
-  const long long rows = (long long)N * T;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, scores, rows, T);
-  DRM_HIP_CHECK(hipGetLastError());
+  DRM_TRY(launch_softmax_rows(scores, (long long)N * T, T, s));
   if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
     hipLaunchKernelGGL((bgemm64s_kernel<false, 1>), dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
                        (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f / 4096.0f, 4096.0f);

@@ -85,6 +85,10 @@ struct ConvArgs {
 #endif
   double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)
   const float* w_inv_scale = nullptr;  // split-precision path: device scalar 2^-k undoing the weight pre-scaling
+  int ld0 = 0;                         // channel stride of src0's pixels when it is a channel slice of a wider tensor (0 = C0)
+  long long w_img_stride_f4 = 0;       // split 1x1 path: every image has its own packed weight set this many float4 apart (attention GEMMs)
+  const float* w_inv_img = nullptr;    // ... and its own 2^-k weight factor [N] (replaces w_inv_scale)
+  int prof_kind = -1;                  // launch-profiler family override (-1 = by tap count, PROF_KINDS = no scope of its own)
   const float* in_inv = nullptr;       // split-precision path: [N] per-image 2^-k undoing the input staging factor (launch_act_pow2_scale)
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
@@ -109,8 +113,10 @@ int chan_moments_splits(int HW, int C);
 // per-image power-of-two staging factor for un-normalised inputs of the split-precision convs (gn.hip)
 int launch_act_pow2_scale(const double2* mom0, int C0, int lo0, int hi0, double cnt0, const double2* mom1, int C1, double cnt1,
                           const unsigned* absmax_bits, int Ctab, int N, float* scale, float* shift, float* inv, hipStream_t s);
+// guard_*: optional fused range-guard tables of the same tensor (act_pow2_scale_kernel's product), cnt0 / cnt1 as there
 int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* mom1, int C1, double inv1, const float* gamma,
-                       const float* beta, int N, float* scale, float* shift, hipStream_t s);
+                       const float* beta, int N, float* scale, float* shift, hipStream_t s, double cnt0 = 0.0, double cnt1 = 0.0,
+                       float* guard_scale = nullptr, float* guard_shift = nullptr, float* guard_inv = nullptr);
 
 // attention (attn.hip): qkv [N][T][3C] -> out [N][T][C]; scores workspace [N][T][T]
 size_t refmap_workspace_bytes(long long n, int res, float thr);
@@ -119,6 +125,12 @@ int launch_refmap_mask_make(const float* colors, const float* normals, long long
 int launch_erode_mask(const unsigned char* mask, int H, int W, int k, unsigned char* out, hipStream_t s);
 // terms: 0 = fp32 MFMA, 3 = fp16 hi/lo split, 1 = plain fp16 operands
 int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms = 0);
+// split-precision attention core on the fused 1x1 conv pipeline (per-image weights = k, v^T); T = H*W must be a multiple of 256
+bool attention_conv_applicable(int T, int C, int H, int W, int terms);
+size_t attention_conv_workspace_floats(int N, int T, int C);
+struct ConvArgs;
+int launch_attention_conv(const float* qkv, const double2* qkv_mom, float* scores, float* out, float* ws, int N, int H, int W, int C, int terms,
+                          hipStream_t s, ConvArgs* proj_guard = nullptr);
 
 // boundary maps and the envmap warp (transform.hip)
 int launch_map_chain(const float* x, float* out, long long per_image, int B, const int32_t* ops, const float* args, int n_ops, const float* lo,

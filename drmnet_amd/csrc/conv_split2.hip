@@ -180,6 +180,7 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 
 struct TilePos {
   int n0, ty0, tx0, co0;
+  long long wofs;  // float4 offset of the tile's weights inside one tap/chunk block: its Cout columns (+ its image's own weight set)
 };
 
 template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     t.ty0 = ty * TH;
     t.tx0 = tx * TW;
     t.co0 = n_tile * C::BN;
+    t.wofs = t.co0 + (long long)t.n0 * a.w_img_stride_f4;  // per-image weights (attention GEMMs): one image per tile
     return t;
   };
   int k_tile = jx;  // index inside this XCD's range
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     const float* src;
     int Cs, coff, up;
     if (c < a.C0) {
-      src = a.src0; Cs = a.C0; coff = c; up = a.up0;
+      src = a.src0; Cs = a.ld0 ? a.ld0 : a.C0; coff = c; up = a.up0;
     } else {
       src = a.src1; Cs = a.C1; coff = c - a.C0; up = 0;
     }
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   const unsigned lds_bs = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Bs));  // LDS byte offset of the ring
   // k-th LDS-DMA instruction (0 .. G_PER-1) of a group
-  auto issue_G1 = [&](int gseq, int g_in_tile, int co0, int k) {
+  auto issue_G1 = [&](int gseq, int g_in_tile, long long co0, int k) {
     const int slot = gseq % R;
     const int chunk = g_in_tile / C::NG, g = g_in_tile - chunk * C::NG;
     const int u = k / C::B_PER, j = k % C::B_PER;
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     const int seg = idx / C::BN, co = idx % C::BN;
     glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
   };
-  auto issue_G = [&](int gseq, int g_in_tile, int co0) {
+  auto issue_G = [&](int gseq, int g_in_tile, long long co0) {
     const int slot = gseq % R;
     const int chunk = g_in_tile / C::NG, g = g_in_tile - chunk * C::NG;
 #pragma unroll
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           tp = decode(x_start + k2);
         }
       }
-      issue_G(gseq++, gi++, tp.co0);
+      issue_G(gseq++, gi++, tp.wofs);
     }
   }
   load_A(cur, 0);
@@ -483,11 +485,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     // (else a harmless re-read)
     auto issue_ahead = [&](int gi0) {
       int gi = gi0 + (R - 1);
-      int co0 = cur.co0;
+      long long co0 = cur.wofs;
       if (gi >= NGT) {
         gi -= NGT;
         if (gi >= NGT) gi %= NGT;
-        co0 = nxt.co0;
+        co0 = nxt.wofs;
       }
       issue_G(gseq, gi, co0);
       ++gseq;
@@ -531,11 +533,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         constexpr bool last_g = (g == C::NG - 1);
         // group R-1 steps ahead: inside this tile, else the matching group of the next tile (else a harmless re-read)
         int d_gi = chunk * C::NG + g + (R - 1);
-        int d_co0 = cur.co0;
+        long long d_co0 = cur.wofs;
         if (d_gi >= NGT) {
           d_gi -= NGT;
           if (d_gi >= NGT) d_gi %= NGT;
-          d_co0 = nxt.co0;
+          d_co0 = nxt.wofs;
         }
         const int d_seq = gseq++;
         const bool a_req = (g == A_G) && a_next;
@@ -637,7 +639,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           ev[g] = (a.emb && first) ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
-          sv[g] = a.in_inv ? inv_scale * a.in_inv[nimg[g]] : inv_scale;  // weight and (per image) input staging factors, both 2^-k
+          // weight and (per image) input staging factors, all 2^-k (attention GEMMs: the "weights" are per image, and in_inv carries alpha)
+          sv[g] = (a.w_inv_img ? a.w_inv_img[nimg[g]] : inv_scale) * (a.in_inv ? a.in_inv[nimg[g]] : 1.0f);
         }
         if (a.res && first && !(ks > 1 && a.res == a.out)) {  // split-K on an in-place residual: `out` already holds it
 #pragma unroll
@@ -768,7 +771,8 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     const double px = (double)a.N * a.H * a.W;
     const double px_in = (double)a.N * ((a.H >> a.up0) * (a.W >> a.up0)) * a.C0 + px * a.C1;
     prof_tag(a.N, a.H, a.W, a.C0 + a.C1, a.Cout);
-    ProfScope ps(TAPS == 9 ? PROF_CONV3 : PROF_CONV1, 2.0 * px * TAPS * cin * cout,
+    DRM_REQUIRE(a.w_img_stride_f4 == 0 || (C::TN == 1 && ks == 1), "per-image weights need one image per tile (H*W a multiple of the 256-pixel tile)");
+    ProfScope ps(a.prof_kind == PROF_KINDS ? -1 : (a.prof_kind >= 0 ? a.prof_kind : (TAPS == 9 ? PROF_CONV3 : PROF_CONV1)), 2.0 * px * TAPS * cin * cout,
                  4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
 #ifdef DRM_S2_STAMP
     // DRM_S2_STAMP_FILE=<path> [DRM_S2_STAMP_BLOCK=<workgroup>] [DRM_S2_STAMP_TILE0=<first recorded tile>]: appends one record

@@ -150,6 +150,7 @@ int run_conv(Ctx& c, ConvArgs& a, const float* wbuf, size_t scale_off, Act* stat
 // split-precision range guard for an un-normalised conv input (see engine.hip)
 int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab);
 // ensure_moments on both sources + gn_finalize into (scale, shift)
-int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift);
+// guard_for (optional): a split conv reading (x0 | x1) un-normalised gets its range-guard tables from the same launch
+int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift, ConvArgs* guard_for = nullptr);
 
 }  // namespace drm

@@ -308,7 +308,7 @@ int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_
 // on the (scale, shift) tables the staging path applies anyway and is undone per image in the epilogue.  Bound source: the
 // per-channel sum-of-squares tables of x0 (channels [lo0, hi0)) and x1, or an absmax word per image.  No-op in fp32 mode.
 int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab) {
-  if (!c.split()) return DRM_OK;
+  if (!c.split() || Ctab % 32 != 0) return DRM_OK;  // (channel counts that are not whole 32-chunks run on the exact-fp32 kernel)
   float* sc = c.ar->alloc<float>((size_t)c.N * Ctab);
   float* sh = c.ar->alloc<float>((size_t)c.N * Ctab);
   float* inv = c.ar->alloc<float>((size_t)c.N);
@@ -324,12 +324,25 @@ int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, con
   return DRM_OK;
 }
 
-int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift) {
+int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift, ConvArgs* guard_for) {
   DRM_TRY(ensure_moments(c, x0));
   if (x1) DRM_TRY(ensure_moments(c, *x1));
+  // the same launch can also produce the range-guard tables of a split conv that reads (x0 | x1) un-normalised (skip_connection)
+  const int Ctot = x0.C + (x1 ? x1->C : 0);
+  float *gs = nullptr, *gh = nullptr, *gi = nullptr;
+  if (guard_for && c.split() && Ctot % 32 == 0) {
+    gs = c.ar->alloc<float>((size_t)c.N * Ctot);
+    gh = c.ar->alloc<float>((size_t)c.N * Ctot);
+    gi = c.ar->alloc<float>((size_t)c.N);
+    guard_for->gn_scale = gs;
+    guard_for->gn_shift = gh;
+    guard_for->in_inv = gi;
+  }
   if (c.dry()) return DRM_OK;
   auto inv = [](const Act& a) { return a.mom_sums ? 1.0 / ((double)(a.H >> a.up) * (a.W >> a.up)) : 1.0; };
-  return launch_gn_finalize(x0.mom, x0.C, inv(x0), x1 ? x1->mom : nullptr, x1 ? x1->C : 0, x1 ? inv(*x1) : 1.0, gamma, beta, c.N, scale, shift, c.s);
+  auto cnt = [](const Act& t) { return t.mom_sums ? 0.0 : (double)(t.H >> t.up) * (t.W >> t.up); };
+  return launch_gn_finalize(x0.mom, x0.C, inv(x0), x1 ? x1->mom : nullptr, x1 ? x1->C : 0, x1 ? inv(*x1) : 1.0, gamma, beta, c.N, scale, shift, c.s,
+                            cnt(x0), x1 ? cnt(*x1) : 0.0, gs, gh, gi);
 }
 
 int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out) {
@@ -344,7 +357,8 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
   Act h1 = new_act(c, r.cout, H, W);
   float* sc2 = c.ar->alloc<float>((size_t)c.N * r.cout);
   float* sh2 = c.ar->alloc<float>((size_t)c.N * r.cout);
-  DRM_TRY(gn_params(c, x0, x1, Wb + r.n1_w, Wb + r.n1_b, sc1, sh1));
+  ConvArgs k;  // skip_connection: 1x1 conv on the raw (un-normalised) block input; its range-guard tables come out of the same launch
+  DRM_TRY(gn_params(c, x0, x1, Wb + r.n1_w, Wb + r.n1_b, sc1, sh1, r.has_skip ? &k : nullptr));
   if (!c.dry()) {
     ConvArgs a;
     a.src0 = x0.p; a.src1 = x1 ? x1->p : nullptr; a.C0 = C0; a.C1 = C1; a.up0 = x0.up;
@@ -356,8 +370,6 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
     DRM_TRY(run_conv(c, a, Wb, r.c1_s, &h1));
   }
   DRM_TRY(gn_params(c, h1, nullptr, Wb + r.n2_w, Wb + r.n2_b, sc2, sh2));
-  ConvArgs k;  // skip_connection: 1x1 conv on the raw (un-normalised) block input
-  if (r.has_skip) DRM_TRY(raw_input_guard(c, k, &x0, 0, C0, x1, nullptr, r.cin));
   if (!c.dry()) {
     const float* res = x0.p;
     if (r.has_skip) {
@@ -390,6 +402,8 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   float* qkv = qkv_act.p;
   float* scores = c.ar->alloc<float>((size_t)c.N * T * T);
   float* att = c.ar->alloc<float>((size_t)c.N * T * C);
+  const bool on_conv = c.split() && attention_conv_applicable(T, C, H, W, c.terms());  // the T >= 512 levels: both GEMMs on the conv pipeline
+  float* aws = on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C)) : nullptr;
   ConvArgs p;  // proj_out: 1x1 conv on the raw attention output, a convex combination of v rows: max |att| <= max |v|
   if (!c.dry()) {
     ConvArgs a;
@@ -397,12 +411,13 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
     a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
     a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.taps = 1; a.Cout = 3 * C; a.out = qkv;
     DRM_TRY(run_conv(c, a, Wb, l.qkv_s, &qkv_act));
-    DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split() ? c.terms() : 0));
+    if (on_conv) DRM_TRY(launch_attention_conv(qkv, qkv_act.mom, scores, att, aws, c.N, H, W, C, c.terms(), c.s, &p));
+    else DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split() ? c.terms() : 0));
   } else {
     qkv_act.mom_valid = true;  // sizing pass: the table is filled by the conv epilogue, no stand-alone moments launch
     qkv_act.mom_sums = true;
   }
-  DRM_TRY(raw_input_guard(c, p, &qkv_act, 2 * C, 3 * C, nullptr, nullptr, C));
+  if (!on_conv) DRM_TRY(raw_input_guard(c, p, &qkv_act, 2 * C, 3 * C, nullptr, nullptr, C));  // (the conv-pipeline core hands p its guard tables)
   if (!c.dry()) {
     p.src0 = att; p.C0 = C; p.N = c.N; p.H = H; p.W = W;
     p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.taps = 1; p.Cout = C; p.res = x.p; p.out = out.p;

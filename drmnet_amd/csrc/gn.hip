@@ -88,14 +88,48 @@ int launch_chan_moments(const float* x, int N, int HW, int C, double* partial, d
 }
 
 // grid N, block 256.  32 groups over the concatenated channel axis [C0 | C1].
+// Optional second product (guard_scale != null): the per-image power-of-two staging tables of the SAME concatenated tensor for a
+// split-precision conv that reads it un-normalised (the ResBlock's skip_connection) -- see act_pow2_scale_kernel; cnt0 / cnt1 =
+// pixels per table entry when a table holds means (0 = raw sums).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restrict__ mom0, int C0, double inv0,
                                                            const double2* __restrict__ mom1, int C1, double inv1,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ scale, float* __restrict__ shift) {
+                                                           float* __restrict__ scale, float* __restrict__ shift, double cnt0, double cnt1,
+                                                           float* __restrict__ guard_scale, float* __restrict__ guard_shift,
+                                                           float* __restrict__ guard_inv) {
   __shared__ float g_mean[32], g_rstd[32];
   const int n = blockIdx.x;
   const int C = C0 + C1, cpg = C / 32;
   const int t = threadIdx.x;
+  if (guard_scale) {
+    __shared__ double red[4];
+    __shared__ float s_scale;
+    double m = 0.0;
+    for (int c = t; c < C; c += 256)
+      m = fmax(m, c < C0 ? mom0[(size_t)n * C0 + c].y * (cnt0 > 0 ? cnt0 : 1.0) : mom1[(size_t)n * C1 + (c - C0)].y * (cnt1 > 0 ? cnt1 : 1.0));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    if (t == 0) {
+      const double bound = sqrt(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
+      int k = 0;
+      if (bound > 0.0 && bound < INFINITY) {
+        int e;
+        frexp(bound, &e);
+        k = 15 - e;
+        k = k > 90 ? 90 : (k < -90 ? -90 : k);
+      }
+      s_scale = ldexpf(1.0f, k);
+      guard_inv[n] = ldexpf(1.0f, -k);
+    }
+    __syncthreads();
+    const float gs = s_scale;
+    for (int c = t; c < C; c += 256) {
+      guard_scale[(size_t)n * C + c] = gs;
+      guard_shift[(size_t)n * C + c] = 0.f;
+    }
+  }
   if (t < 32) {
     double m = 0.0, q = 0.0;
     for (int k = 0; k < cpg; ++k) {
@@ -181,9 +215,11 @@ int launch_act_pow2_scale(const double2* mom0, int C0, int lo0, int hi0, double 
 }
 
 int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* mom1, int C1, double inv1, const float* gamma,
-                       const float* beta, int N, float* scale, float* shift, hipStream_t s) {
+                       const float* beta, int N, float* scale, float* shift, hipStream_t s, double cnt0, double cnt1, float* guard_scale,
+                       float* guard_shift, float* guard_inv) {
   DRM_REQUIRE((C0 + C1) % 32 == 0, "GroupNorm32 needs channels % 32 == 0");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, mom0, C0, inv0, mom1, C1, inv1, gamma, beta, scale, shift);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, mom0, C0, inv0, mom1, C1, inv1, gamma, beta, scale, shift, cnt0, cnt1, guard_scale,
+                     guard_shift, guard_inv);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }

@@ -14,8 +14,9 @@ __device__ __forceinline__ float silu_m(float v) { return v / (1.0f + __expf(-v)
 // ---------------------------------------------------------------------------------------------
 // One thread per (pixel, 4-channel quad): the NHWC writes are fully coalesced 16-byte stores; only the first
 // (Cx + Cc + 3) / 4 quads read anything.
-// grid (blocks over one image, N): a block never straddles two images, so the optional per-image absmax is one wave
-// reduction + one atomicMax per wave (non-negative floats order like their bit patterns).
+// grid (blocks over one image, N): a block never straddles two images, so the optional per-image absmax is a block reduction and
+// at most ONE atomicMax per block (non-negative floats order like their bit patterns) -- skipped when the word already holds a
+// value at least as large (a stale read only costs a redundant atomic; same-address atomics serialise at the memory side).
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ cond, const int* __restrict__ idx,
                                                           float4* __restrict__ out, int N, int HW, int Cx, int Cc, int Q,
                                                           unsigned* __restrict__ absmax_bits) {
@@ -37,11 +38,18 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
   }
   if (live) out[i] = make_float4(v[0], v[1], v[2], v[3]);
   if (absmax_bits) {
+    __shared__ float wmax[4];
     float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     if (!(m == m)) m = INFINITY;  // NaN input: no finite bound
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax_bits + n, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(absmax_bits + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(absmax_bits + n, __float_as_uint(m));
+    }
   }
 }
 

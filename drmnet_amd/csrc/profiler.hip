@@ -31,7 +31,7 @@ void prof_enable(int on) { g_on = on < 0 ? 0 : on; }
 bool prof_enabled() { return g_on != 0; }
 
 ProfScope::ProfScope(int k, double flops, double bytes, hipStream_t st) : kind(k), slot(-1), s(st) {
-  if (!g_on || (g_on == 2 && k != PROF_CONV3)) return;
+  if (!g_on || k < 0 || (g_on == 2 && k != PROF_CONV3)) return;  // k < 0: the launch sits inside an enclosing scope
   if (g_used == g_pool.size()) {
     Rec r{};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
