@@ -28,7 +28,7 @@ SYMBOLS = [
     "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddpm_sample", "drm_randn",
     "drm_profile_enable", "drm_profile_reset", "drm_profile_collect", "drm_unet_set_precision", "drm_set_op_precision",
     "drm_refmap_workspace_bytes", "drm_refmap_mask_make", "drm_erode_mask",
-    "drm_unet_load_params_set", "drm_unet_use_set",
+    "drm_unet_load_params_set", "drm_unet_use_set", "drm_set_graph_replay", "drm_graph_launches",
     "drm_map_chain", "drm_masked_log_range", "drm_luminance_scale", "drm_mirmap2envmap", "drm_hdr2ldr",
 ]
 
@@ -103,6 +103,8 @@ def lib() -> C.CDLL:
     L.drm_profile_enable.restype = None
     L.drm_profile_reset.restype = None
     L.drm_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.drm_set_graph_replay.argtypes = [i32]
+    L.drm_graph_launches.restype = C.c_int64
     L.drm_map_chain.argtypes = [fp, fp, C.c_int64, i32, C.POINTER(C.c_int32), C.POINTER(C.c_float), i32, fp, fp, fp, vp]
     L.drm_masked_log_range.argtypes = [fp, fp, i32, i32, i32, fp, fp, vp]
     L.drm_luminance_scale.argtypes = [fp, i32, i32, C.c_float, fp, vp]

@@ -412,6 +412,12 @@ int drm_set_op_precision(int precision) {
   });
 }
 
+int drm_set_graph_replay(int on) {
+  set_graph_replay(on != 0);
+  return DRM_OK;
+}
+int64_t drm_graph_launches(void) { return (int64_t)graph_launches(); }
+
 void drm_profile_enable(int on) { prof_enable(on); }
 void drm_profile_reset(void) { prof_reset(); }
 int drm_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches) {

@@ -10,6 +10,7 @@
 // Noise is either an external buffer (parity mode; the reference's draws are data dependent) or the
 // library's counter-based Philox4x32-10 stream (throughput mode), selected by a null pointer.
 #include "samplers.h"
+#include "profiler.h"
 
 #include <cmath>
 #include <vector>
@@ -141,32 +142,48 @@ __global__ void drmnet_record_kernel(const int32_t* __restrict__ rows, const int
 
 // ------------------------------------------------------------------------------------------------ DDIM / DDPM kernels
 
+// DDIM / DDPM loops keep every per-step scalar in a DEVICE table (row j: timestep, five coefficients) indexed by a device
+// counter, so the launches of a step do not depend on j and one captured hipGraph of a step can be replayed for the whole chain
+// (BASELINE configs[2]: "hipGraph-captured step").  Table row layout: STEP_ROW floats.
+constexpr int STEP_ROW = 8;  // [0] timestep, [1..5] coefficients, [6] flag (DDPM: t > 0), [7] unused
+
+__global__ void step_begin_kernel(const float* __restrict__ tab, const int* __restrict__ counter, float* __restrict__ tf, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) tf[i] = tab[(size_t)(*counter) * STEP_ROW];
+}
+__global__ void step_advance_kernel(int* counter) { *counter += 1; }
+
 // pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);  x = sqrt(a_prev) pred_x0 + sqrt(1-a_prev-s^2) e + s * noise   (ddim.py:249-258)
-__global__ void ddim_update_kernel(float* __restrict__ x, const float* __restrict__ e, const float* __restrict__ noise, size_t n, float sa,
-                                   float s1m, float sap, float sdir, float sig, uint64_t seed, uint64_t noise_off) {
+__global__ void ddim_update_kernel(float* __restrict__ x, const float* __restrict__ e, const float* __restrict__ noise, size_t n,
+                                   const float* __restrict__ tab, const int* __restrict__ counter, uint64_t seed) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int j = *counter;
+  const float* c = tab + (size_t)j * STEP_ROW + 1;
+  const float sa = c[0], s1m = c[1], sap = c[2], sdir = c[3], sig = c[4];
   const float xv = x[i], ev = e[i];
   const float pred = (xv - s1m * ev) / sa;
   float nz = 0.f;
-  if (sig != 0.f) nz = noise ? noise[i] : philox_normal1(seed, noise_off + i);
+  if (sig != 0.f) nz = noise ? noise[(size_t)j * n + i] : philox_normal1(seed, (uint64_t)(j + 1) * n + i);
   x[i] = sap * pred + sdir * ev + sig * nz;
 }
 
 // x_recon = c0 x - c1 e; mean = c2 x_recon + c3 x; x = mean + [t>0] c4 noise   (ddpm.py:233-246,1156-1167)
 __global__ void ddpm_update_kernel(float* __restrict__ x, float* __restrict__ pred_x0, const float* __restrict__ e,
-                                   const float* __restrict__ noise, size_t n, float c0, float c1, float c2, float c3, float c4, int nonzero,
-                                   int clip, uint64_t seed, uint64_t noise_off) {
+                                   const float* __restrict__ noise, size_t n, const float* __restrict__ tab, const int* __restrict__ counter,
+                                   int clip, uint64_t seed) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int j = *counter;
+  const float* c = tab + (size_t)j * STEP_ROW + 1;
   const float xv = x[i];
-  float xr = c0 * xv - c1 * e[i];
+  float xr = c[0] * xv - c[1] * e[i];
   if (clip) xr = fminf(fmaxf(xr, -1.f), 1.f);
-  const float mean = c2 * xr + c3 * xv;
+  const float mean = c[2] * xr + c[3] * xv;
   float v = mean;
-  if (nonzero) {
-    const float nz = noise ? noise[i] : philox_normal1(seed, noise_off + i);
-    v += c4 * nz;
+  if (c[5] != 0.f) {
+    const float nz = noise ? noise[(size_t)j * n + i] : philox_normal1(seed, (uint64_t)(j + 1) * n + i);
+    v += c[4] * nz;
   }
   x[i] = v;
   if (pred_x0) pred_x0[i] = xr;
@@ -322,54 +339,155 @@ size_t sampler_workspace_bytes(UNet* net, int N, int H, int W) {
   a.dry = true;
   if (net->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a, nullptr) != DRM_OK) return 0;
   const size_t chw = (size_t)net->desc.out_channels * H * W;
-  return a.peak + ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + 512;
+  // U-Net arena + eps [N,C,H,W] + timesteps [N] + the per-step scalar table (<= 4096 steps) and its counter
+  return a.peak + ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + (4096 * 8 * sizeof(float) + 256) + 1024;
+}
+
+// Runs `steps` identical-launch steps: the first eagerly (it also sizes caches and sets per-kernel attributes), the second under
+// stream capture, the rest as replays of that graph.  Falls back to eager launches when replay is switched off, the launch
+// profiler is recording (its events do not belong in a graph) or the chain is too short to pay for an instantiation.
+static bool g_graph_replay = true;
+static long long g_graph_launches = 0;
+void set_graph_replay(bool on) { g_graph_replay = on; }
+long long graph_launches() { return g_graph_launches; }
+
+static bool graph_wanted(int steps) { return g_graph_replay && !prof_enabled() && steps >= 4; }
+
+// The legacy default stream (what PyTorch hands over unless the caller set a stream) cannot be captured: a chain that will be
+// replayed runs on a private non-blocking stream ordered behind the caller's stream by an event; run_steps drains it before it
+// returns, so work the caller enqueues afterwards on its own stream is ordered behind the chain.
+static int chain_stream(hipStream_t caller, int steps, hipStream_t* out) {
+  *out = caller;
+  if (caller != nullptr || !graph_wanted(steps)) return DRM_OK;
+  static thread_local hipStream_t priv = nullptr;
+  static thread_local hipEvent_t ev = nullptr;
+  if (!priv) {
+    DRM_HIP_CHECK(hipStreamCreateWithFlags(&priv, hipStreamNonBlocking));
+    DRM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  DRM_HIP_CHECK(hipEventRecord(ev, caller));
+  DRM_HIP_CHECK(hipStreamWaitEvent(priv, ev, 0));
+  *out = priv;
+  return DRM_OK;
+}
+
+template <typename Body>
+static int run_steps(int steps, hipStream_t s, Body&& body) {
+  const bool use_graph = graph_wanted(steps);
+  if (!use_graph) {
+    for (int j = 0; j < steps; ++j) DRM_TRY(body());
+    return DRM_OK;
+  }
+  DRM_TRY(body());
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  DRM_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  const hipError_t ec = hipStreamEndCapture(s, &graph);
+  if (rc != DRM_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  DRM_HIP_CHECK(ec);
+  hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (ei != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    DRM_HIP_CHECK(ei);
+  }
+  int status = DRM_OK;
+  for (int j = 1; j < steps && status == DRM_OK; ++j) {
+    if (hipGraphLaunch(exec, s) != hipSuccess) {
+      set_error("hipGraphLaunch failed while replaying a sampler step");
+      status = DRM_ERR_HIP;
+    }
+    ++g_graph_launches;
+  }
+  // the executable graph must outlive its last launch: the stream is drained before it is destroyed
+  if (hipStreamSynchronize(s) != hipSuccess && status == DRM_OK) {
+    set_error("stream error while replaying sampler steps");
+    status = DRM_ERR_HIP;
+  }
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  return status;
+}
+
+// uploads the per-step table (host rows -> device) and zeroes the step counter
+static int upload_step_table(const std::vector<float>& rows, float* tab, int* counter, hipStream_t s) {
+  DRM_HIP_CHECK(hipMemcpyAsync(tab, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  DRM_HIP_CHECK(hipStreamSynchronize(s));  // `rows` is pageable host memory owned by the caller's frame
+  DRM_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
+  return DRM_OK;
 }
 
 int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
-                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s) {
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddim needs a UNetModel");
   DRM_REQUIRE(S >= 1 && timesteps && coef, "ddim schedule");
   const int Cx = net->desc.out_channels, Cc = net->desc.in_channels - Cx;
   const size_t n = (size_t)N * Cx * H * W;
+  const int steps = (num_steps > 0 && num_steps < S) ? num_steps : S;
+  hipStream_t s;
+  DRM_TRY(chain_stream(caller, steps, &s));
   float* e = ar.alloc<float>(n);
   float* tf = ar.alloc<float>((size_t)N);
+  float* tab = ar.alloc<float>((size_t)steps * STEP_ROW);
+  int* counter = ar.alloc<int>(1);
   if (ar.failed) { set_error("ddim: workspace too small"); return DRM_ERR_WORKSPACE; }
-  const size_t mark = ar.mark();
-  const int steps = (num_steps > 0 && num_steps < S) ? num_steps : S;
+  std::vector<float> rows((size_t)steps * STEP_ROW, 0.f);
   for (int j = 0; j < steps; ++j) {
     const int index = S - 1 - j;
-    DRM_TRY(fill_f32(tf, N, (float)timesteps[index], s));
+    rows[(size_t)j * STEP_ROW] = (float)timesteps[index];
+    for (int k = 0; k < 5; ++k) rows[(size_t)j * STEP_ROW + 1 + k] = coef[5 * index + k];
+  }
+  DRM_TRY(upload_step_table(rows, tab, counter, s));
+  const size_t mark = ar.mark();
+  return run_steps(steps, s, [&]() -> int {
+    hipLaunchKernelGGL(step_begin_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tab, counter, tf, N);
+    DRM_HIP_CHECK(hipGetLastError());
     ar.release(mark);
     DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
-    const float* c = coef + 5 * index;
-    hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, e, noise ? noise + (size_t)j * n : nullptr, n,
-                       c[0], c[1], c[2], c[3], c[4], seed, (uint64_t)(j + 1) * n);
+    hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, e, noise, n, tab, counter, seed);
     DRM_HIP_CHECK(hipGetLastError());
-  }
-  return DRM_OK;
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);
+    DRM_HIP_CHECK(hipGetLastError());
+    return DRM_OK;
+  });
 }
 
 int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip, const float* noise,
-                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s) {
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddpm needs a UNetModel");
   DRM_REQUIRE(T_start >= 1 && coef, "ddpm schedule");
+  hipStream_t s;
+  DRM_TRY(chain_stream(caller, T_start, &s));
   const int Cx = net->desc.out_channels, Cc = net->desc.in_channels - Cx;
   const size_t n = (size_t)N * Cx * H * W;
   float* e = ar.alloc<float>(n);
   float* tf = ar.alloc<float>((size_t)N);
+  float* tab = ar.alloc<float>((size_t)T_start * STEP_ROW);
+  int* counter = ar.alloc<int>(1);
   if (ar.failed) { set_error("ddpm: workspace too small"); return DRM_ERR_WORKSPACE; }
-  const size_t mark = ar.mark();
+  std::vector<float> rows((size_t)T_start * STEP_ROW, 0.f);
   for (int j = 0; j < T_start; ++j) {
     const int t = T_start - 1 - j;
-    DRM_TRY(fill_f32(tf, N, (float)t, s));
+    rows[(size_t)j * STEP_ROW] = (float)t;
+    for (int k = 0; k < 5; ++k) rows[(size_t)j * STEP_ROW + 1 + k] = coef[5 * t + k];
+    rows[(size_t)j * STEP_ROW + 6] = t != 0 ? 1.f : 0.f;  // no noise at t == 0 (ddpm.py:1161)
+  }
+  DRM_TRY(upload_step_table(rows, tab, counter, s));
+  const size_t mark = ar.mark();
+  return run_steps(T_start, s, [&]() -> int {
+    hipLaunchKernelGGL(step_begin_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tab, counter, tf, N);
+    DRM_HIP_CHECK(hipGetLastError());
     ar.release(mark);
     DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
-    const float* c = coef + 5 * t;
-    hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, pred_x0, e,
-                       noise ? noise + (size_t)j * n : nullptr, n, c[0], c[1], c[2], c[3], c[4], t != 0 ? 1 : 0, clip, seed, (uint64_t)(j + 1) * n);
+    hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, pred_x0, e, noise, n, tab, counter, clip, seed);
     DRM_HIP_CHECK(hipGetLastError());
-  }
-  return DRM_OK;
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);
+    DRM_HIP_CHECK(hipGetLastError());
+    return DRM_OK;
+  });
 }
 
 }  // namespace drm

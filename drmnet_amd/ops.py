@@ -20,6 +20,15 @@ def set_precision(precision: str) -> None:
     _lib.check(_lib.lib().drm_set_op_precision(modes[precision]))
 
 
+def set_graph_replay(on: bool) -> None:
+    """DDIM / DDPM chains replay one captured hipGraph of a step (default on); see include/drmnet_hip.h."""
+    _lib.check(_lib.lib().drm_set_graph_replay(int(bool(on))))
+
+
+def graph_launches() -> int:
+    return int(_lib.lib().drm_graph_launches())
+
+
 def _dev(t: torch.Tensor):
     return torch.cuda.device(t.device)
 

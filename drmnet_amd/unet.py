@@ -128,13 +128,13 @@ class _HipUNetBase(nn.Module):
         return torch.ones(shape) if key.endswith("weight") else torch.zeros(shape)
 
     def __del__(self):
-        h = getattr(self, "_h", None)
-        if h is not None and h.value:
-            try:
+        try:  # (at interpreter shutdown module globals may already be gone)
+            h = self.__dict__.get("_h")
+            if h is not None and h.value:
                 _lib.lib().drm_unet_destroy(h)
-            except Exception:
-                pass
-            self._h = None
+                self.__dict__["_h"] = None
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ arithmetic mode
     PRECISIONS = {"fp32": 0, "f16x3": 1, "f16": 2}

@@ -160,7 +160,8 @@ int drm_drmnet_sample(drm_drmnet* s, const float* LrK, const float* cond, const 
 
 /* DDIM sampling (DDIMSampler.ddim_sampling + p_sample_ddim, ldm/models/diffusion/ddim.py:128-259).
  *   timesteps: int64[S] (host) ddim_timesteps; coef: float[S][5] (host) = sqrt(a_t), sqrt(1-a_t), sqrt(a_prev),
- *   sqrt(1-a_prev-sigma^2), sigma per index; runs index S-1 .. 0 (or the first num_steps of them).
+ *   sqrt(1-a_prev-sigma^2), sigma per index; runs index S-1 .. 0 (or the first num_steps of them).  Synchronises the stream once
+ *   at entry (upload of the per-step table).
  *   x: [N,3,H,W] in = x_T, out = final x;  cond: [N,3,H,W];  noise: [steps,N,3,H,W] or NULL (Philox). */
 int drm_ddim_sample(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
                     const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
@@ -173,6 +174,14 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
                     const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 
 size_t drm_sampler_workspace_bytes(const drm_unet* net, int N, int H, int W);
+
+/* drm_ddim_sample / drm_ddpm_sample keep every per-step scalar (timestep, coefficients, noise offset) in a device table indexed
+ * by a device counter, so all steps issue the same launches: the first step runs eagerly, the second is captured into a hipGraph
+ * and the rest of the chain replays it (BASELINE configs[2] "hipGraph-captured step").  On by default for chains of >= 4 steps;
+ * off while the launch profiler records (events do not belong in a graph).  With replay the call returns after the chain has
+ * finished (the executable graph is destroyed behind its last launch).  drm_graph_launches counts hipGraphLaunch calls so far. */
+int drm_set_graph_replay(int on);
+int64_t drm_graph_launches(void);
 
 /* Launch profiler (HIP events on the launch stream around each kernel family; used by bench.py for the roofline
  * object).  Kinds: 0 conv3x3 (fused GN+SiLU+conv implicit GEMM), 1 conv1x1 (skip / qkv / proj), 2 attention core,

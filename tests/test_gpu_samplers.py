@@ -139,3 +139,31 @@ def test_step_dropins_match_reference_named_methods(dev):
     out_ref = x + ou.unet_forward(Pu, tu, xc, t_emb=ou.z_embed(Pz, zk - torch.from_numpy(g["z0"])))
     assert delta == float(g["delta"])
     assert rel_l2(z_out.cpu(), z_ref) < 2e-5 and rel_l2(mean.cpu(), out_ref) < 2e-5
+
+
+def test_graph_replayed_chain_equals_eager_chain(dev):
+    """drm_ddim_sample / drm_ddpm_sample: step 1 eager, step 2 captured, the rest replayed (per-step scalars in a device table)
+    must be bit-identical to the all-eager chain, with injected noise and with the Philox stream."""
+    from drmnet_amd import ops
+    from drmnet_amd.ddim import DDIMSampler
+
+    g = gold("ddim_trace_eta1")
+    m = tiny_obsnet(dev).set_precision("f16x3")
+    cond, x_T, noise = (torch.from_numpy(g[k]).to(dev) for k in ("cond", "x_T", "noise"))
+    s = DDIMSampler(m)
+    run = lambda **kw: s.sample(50, cond.shape[0], (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, **kw)[0]
+    try:
+        ops.set_graph_replay(False)
+        n0 = ops.graph_launches()
+        eager, eager_p = run(noise=noise), run(seed=11)
+        assert ops.graph_launches() == n0
+        ops.set_graph_replay(True)
+        graphed, graphed_p = run(noise=noise), run(seed=11)
+        assert ops.graph_launches() == n0 + 2 * 49
+        assert torch.equal(graphed, eager) and torch.equal(graphed_p, eager_p)
+        assert rel_l2(graphed.cpu(), g["x"]) < 2e-4  # and still the reference's trace
+        d_e = (ops.set_graph_replay(False), m.p_sample_loop(cond, tuple(x_T.shape), x_T=x_T, verbose=False, start_T=7, seed=5))[1]
+        d_g = (ops.set_graph_replay(True), m.p_sample_loop(cond, tuple(x_T.shape), x_T=x_T, verbose=False, start_T=7, seed=5))[1]
+        assert torch.equal(d_e, d_g)
+    finally:
+        ops.set_graph_replay(True)
