@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="refmaps per GPU (BASELINE config[1]: 32)")
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
-    ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim", "estimate_chain"])
+    ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim", "obsnet_ddim_chain", "estimate_chain"])
     ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "f16"],
                     help="conv arithmetic: f16x3 (default) = every fp32 operand split into fp16 hi+lo, 3 MFMAs per product, fp32 "
                          "accumulate: passes the SAME parity tolerances as fp32 (tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32")
@@ -158,12 +158,23 @@ def make_step(args, model, dev):
                 unet.forward_parts(xk, x, timesteps=t)
 
         return step, GFLOP[args.workload].get(key, 0), f"{args.workload} U-Net forward"
-    # obsnet_ddim: one DDIM step (U-Net + fused update, Philox noise)
+    # obsnet_ddim: one DDIM step (U-Net + fused update, Philox noise); obsnet_ddim_chain: the whole 50-step chain with the
+    # captured-step hipGraph replay (BASELINE configs[2]: DDIM 50-step, batch 256, reduced precision, graph) -- one bench step = one chain
+    from drmnet_amd import ops
     from drmnet_amd.ddim import DDIMSampler
 
     s = DDIMSampler(model)
     s.make_schedule(50, ddim_eta=1.0, verbose=False)
     xT = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+    if args.workload == "obsnet_ddim_chain":
+        ops.set_graph_replay(True)
+
+        def chain():
+            out, _ = s.ddim_sampling(x, tuple(x.shape), x_T=xT, seed=1)
+            chain.state = out
+
+        chain.units = 50  # denoise steps per bench step and sample
+        return chain, GFLOP["obsnet"].get(key, 0), "ObsNet DDIM chain, 50 steps (eta = 1, Philox noise), step 2 captured as a hipGraph and replayed"
 
     def step():
         s.ddim_sampling(x, tuple(x.shape), x_T=xT, num_steps=1, seed=1)
@@ -403,7 +414,7 @@ def main():
             step()
         barrier()
         L.drm_profile_enable(0)
-    dt, total_units = rank_aggregate(dt, float(args.batch * args.steps), dist, dev)
+    dt, total_units = rank_aggregate(dt, float(args.batch * args.steps * getattr(step, "units", 1)), dist, dev)
 
     roofline = None
     breakdown = None

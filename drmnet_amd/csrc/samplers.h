@@ -31,7 +31,7 @@ class DrmnetSampler {
 };
 
 size_t sampler_workspace_bytes(UNet* net, int N, int H, int W);
-void set_graph_replay(bool on);   // DDIM / DDPM chains: replay one captured hipGraph of a step (default on)
+void set_graph_replay(bool on);   // DDIM / DDPM chains: replay one captured hipGraph of a step (default off)
 long long graph_launches();       // hipGraphLaunch calls made so far (tests / bench read it)
 int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
                 uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s);

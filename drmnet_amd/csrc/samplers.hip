@@ -346,7 +346,7 @@ size_t sampler_workspace_bytes(UNet* net, int N, int H, int W) {
 // Runs `steps` identical-launch steps: the first eagerly (it also sizes caches and sets per-kernel attributes), the second under
 // stream capture, the rest as replays of that graph.  Falls back to eager launches when replay is switched off, the launch
 // profiler is recording (its events do not belong in a graph) or the chain is too short to pay for an instantiation.
-static bool g_graph_replay = true;
+static bool g_graph_replay = false;  // measured: no faster at B = 32 / 256 (kernels already cover ~95 % of the wall time), slower at B = 1
 static long long g_graph_launches = 0;
 void set_graph_replay(bool on) { g_graph_replay = on; }
 long long graph_launches() { return g_graph_launches; }

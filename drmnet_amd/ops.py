@@ -21,7 +21,7 @@ def set_precision(precision: str) -> None:
 
 
 def set_graph_replay(on: bool) -> None:
-    """DDIM / DDPM chains replay one captured hipGraph of a step (default on); see include/drmnet_hip.h."""
+    """DDIM / DDPM chains replay one captured hipGraph of a step (default off); see include/drmnet_hip.h."""
     _lib.check(_lib.lib().drm_set_graph_replay(int(bool(on))))
 
 

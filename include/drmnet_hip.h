@@ -177,8 +177,9 @@ size_t drm_sampler_workspace_bytes(const drm_unet* net, int N, int H, int W);
 
 /* drm_ddim_sample / drm_ddpm_sample keep every per-step scalar (timestep, coefficients, noise offset) in a device table indexed
  * by a device counter, so all steps issue the same launches: the first step runs eagerly, the second is captured into a hipGraph
- * and the rest of the chain replays it (BASELINE configs[2] "hipGraph-captured step").  On by default for chains of >= 4 steps;
- * off while the launch profiler records (events do not belong in a graph).  With replay the call returns after the chain has
+ * and the rest of the chain replays it (BASELINE configs[2] "hipGraph-captured step").  Off by default (measured on MI355X:
+ * within +-0.5 % of eager launches at batch 32 / 256, 4-8 % slower at batch 1 where the instantiation is not amortised); when on
+ * it applies to chains of >= 4 steps and steps aside while the launch profiler records (events do not belong in a graph).  With replay the call returns after the chain has
  * finished (the executable graph is destroyed behind its last launch).  drm_graph_launches counts hipGraphLaunch calls so far. */
 int drm_set_graph_replay(int on);
 int64_t drm_graph_launches(void);

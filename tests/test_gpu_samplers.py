@@ -166,4 +166,4 @@ def test_graph_replayed_chain_equals_eager_chain(dev):
         d_g = (ops.set_graph_replay(True), m.p_sample_loop(cond, tuple(x_T.shape), x_T=x_T, verbose=False, start_T=7, seed=5))[1]
         assert torch.equal(d_e, d_g)
     finally:
-        ops.set_graph_replay(True)
+        ops.set_graph_replay(False)
