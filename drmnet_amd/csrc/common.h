@@ -77,7 +77,8 @@ struct ConvArgs {
   float* out = nullptr;             // NHWC [N,H,W,Cout], or NCHW [N,cout_valid,H,W] if out_nchw
   int out_nchw = 0, cout_valid = 0;
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
-  int ksplit = 1;                      // split-K factor (conv_split_ksplit); > 1: partial results are added into `out`
+  int ksplit = 1;                      // split-K factor (conv_split_ksplit); > 1: split k writes its raw partial sums to out + k * split_stride
+  size_t split_stride = 0;             // floats between the split-K slabs (0 unless ksplit > 1)
   int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 1 = plain fp16 operands
 #ifdef DRM_S2_STAMP
   unsigned* stamp_out = nullptr;       // diagnostic build: [8 waves][128][2] (id, s_memtime low word) of one workgroup
@@ -95,6 +96,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s);
 // split-precision (fp16 hi/lo x 3 MFMA, fp32-accurate) variant; a.w = pre-split weights (conv_split.hip)
 int launch_conv_split(const ConvArgs& a, hipStream_t s);
 int conv_split_ksplit(const ConvArgs& a);  // split-K factor the split kernels want for this launch (1 = none)
+// deterministic second half of a split-K conv: out = sum of the slabs at `partial` (+ bias, emb, residual), statistics into a.stat_out
+int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s);
 bool conv_split_fuses_stats();  // true when the active split kernel accumulates ConvArgs::stat_out in its epilogue
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);
 int launch_pack_conv_weight_split(const float* w, float* packed, float* scales, unsigned* scratch, int Cout, int Cin, int taps, int CoutP,

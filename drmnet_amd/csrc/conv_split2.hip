@@ -235,13 +235,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 
   const int Ctot = a.C0 + a.C1;
   // split-K (deep, small maps: too few output tiles to fill the chip, long K): blockIdx.y owns a contiguous range of the
-  // 32-channel chunks and ADDS its partial result into the pre-zeroed output; bias / emb / residual come from split 0
+  // 32-channel chunks and writes its partial result to its own slab; a fixed-order reduction sums the slabs (deterministic)
   const int nch_all = Ctot / C::KC;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   const int split = blockIdx.y;
   const int chunk0 = split * nch_all / ks;
   const int nchunks = (split + 1) * nch_all / ks - chunk0;  // chunks of THIS workgroup (indices below are local)
   const int NGT = nchunks * C::NG;  // weight groups (pipeline steps) per tile
+  float* const out_s = a.out + (size_t)split * a.split_stride;  // split-K: this split's partial slab (split_stride = 0 otherwise)
   const bool has_gn = a.gn_scale != nullptr;
 
   // ---- activation loader (ordinary loads, always issued: addresses are clamped, invalid slots zeroed at store time)
@@ -633,7 +634,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       for (int c = 0; c < NT; ++c) {
         const int col = (wn * NT + c) * 32 + r;
         const int co = cur.co0 + col;
-        const bool first = split == 0;
+        // split-K: every split writes its raw partial sums to its own slab (a.out + split * slab); bias / emb / residual and the
+        // statistics are applied by the fixed-order reduction that follows (splitk_reduce_kernel)
+        const bool first = ks == 1;
         const float bias = (a.bias && first) ? a.bias[co] : 0.f;
         float rv[16], ev[4], sv[4];
 #pragma unroll
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           // weight and (per image) input staging factors, all 2^-k (attention GEMMs: the "weights" are per image, and in_inv carries alpha)
           sv[g] = (a.w_inv_img ? a.w_inv_img[nimg[g]] : inv_scale) * (a.in_inv ? a.in_inv[nimg[g]] : 1.0f);
         }
-        if (a.res && first && !(ks > 1 && a.res == a.out)) {  // split-K on an in-place residual: `out` already holds it
+        if (a.res && first) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) rv[e] = a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co];
         } else {
@@ -666,20 +669,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             }
           }
         }
-        if (a.out_nchw || ks > 1) {
+        if (a.out_nchw) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int g = e >> 2;
-            if (!okg[g]) continue;
-            if (a.out_nchw) {
-              if (co < a.cout_valid) {
-                const size_t pix = pixb[g] + (e & 3);
-                const size_t hw = (size_t)a.H * a.W;
-                a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v[e];
-              }
-            } else {
-              unsafeAtomicAdd(&a.out[(pixb[g] + (e & 3)) * a.Cout + co], v[e]);  // global_atomic_add_f32, no return
-            }
+            if (!okg[g] || co >= a.cout_valid) continue;
+            const size_t pix = pixb[g] + (e & 3);
+            const size_t hw = (size_t)a.H * a.W;
+            a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v[e];
           }
         } else {
           // NHWC store, 16 bytes per lane: the accumulator layout gives a lane ONE channel of four consecutive pixels per row
@@ -690,7 +687,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], r);
-            if (okg[g]) *reinterpret_cast<float4*>(&a.out[(pixb[g] + (r & 3)) * a.Cout + cq]) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            if (okg[g]) *reinterpret_cast<float4*>(&out_s[(pixb[g] + (r & 3)) * a.Cout + cq]) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
           }
         }
         if (st) {
@@ -761,11 +758,8 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
   long long grid = (long long)di->cus * per_cu;
   const int ngt = ((a.C0 + a.C1) / C::KC) * C::NG;  // weight groups per tile
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  DRM_REQUIRE(ks == 1 || (TAPS == 9 && !a.out_nchw && !a.stat_out && ((a.C0 + a.C1) / C::KC) / ks >= 1), "split-K launch contract");
+  DRM_REQUIRE(ks == 1 || (TAPS == 9 && !a.out_nchw && !a.stat_out && a.split_stride > 0 && ((a.C0 + a.C1) / C::KC) / ks >= 1), "split-K launch contract");
   if (tiles < grid || ngt < R - 1 || (TAPS == 1 && ngt < 2) || ks > 1) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
-  // partial results are ADDED into the output: it starts from zero -- or, for an in-place residual (res == out, the ResBlock
-  // skip-conv case), from the residual itself
-  if (ks > 1 && a.res != a.out) DRM_HIP_CHECK(hipMemsetAsync(a.out, 0, (size_t)a.N * a.H * a.W * a.Cout * sizeof(float), s));
   {
     const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
     const double px = (double)a.N * a.H * a.W;
@@ -857,6 +851,61 @@ int conv_split_ksplit(const ConvArgs& a) {
   const int nch = (a.C0 + a.C1) / 32;
   const long long ks = std::min<long long>(std::min<long long>(8, nch / 4), 640 / std::max<long long>(tiles, 1));
   return (int)std::max<long long>(ks, 1);
+}
+
+// Fixed-order sum of the split-K slabs (already un-scaled by their launch) + everything the conv epilogue would have added: out = sum_k partial[k] + bias
+// (+ emb[n] + residual), and the per-(image, channel) sums / sums of squares of the result for the next GroupNorm.  The slab
+// order is fixed, so the result does not depend on which workgroup finished first (the atomic accumulation it replaces did).
+// grid (pixel blocks, N), block 256: thread = (channel quad, pixel lane); per-thread fp32 partial statistics, one fp64 atomic per
+// (thread, channel, moment) at the end (fp64 adds of a handful of terms: order effects sit at 2^-53).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ partial, size_t slab_f4, int ks, const float* __restrict__ bias,
+                                                            const float* __restrict__ emb, int emb_stride, const float* __restrict__ res,
+                                                            float4* __restrict__ out, double2* __restrict__ stat, int HW, int Cout, int px_per_block) {
+  const int n = blockIdx.y, q4 = Cout >> 2;
+  const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, HW);
+  for (int q = threadIdx.x % 64; q < q4; q += 64) {  // 64 channel quads x 4 pixel lanes per pass
+    float4 b = bias ? reinterpret_cast<const float4*>(bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (emb) {
+      const float4 e = *reinterpret_cast<const float4*>(emb + (size_t)n * emb_stride + 4 * q);
+      b.x += e.x; b.y += e.y; b.z += e.z; b.w += e.w;
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + threadIdx.x / 64; p < p1; p += 4) {
+      const size_t idx = ((size_t)n * HW + p) * q4 + q;
+      float4 acc = partial[idx];
+      for (int k = 1; k < ks; ++k) {
+        const float4 t = partial[idx + (size_t)k * slab_f4];
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+      float4 v = make_float4(acc.x + b.x, acc.y + b.y, acc.z + b.z, acc.w + b.w);
+      if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res)[idx];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      out[idx] = v;
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
+    }
+    if (stat) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double* d = reinterpret_cast<double*>(stat + (size_t)n * Cout + 4 * q + k);
+        atomicAdd(d, (double)s[k]);
+        atomicAdd(d + 1, (double)ss[k]);
+      }
+    }
+  }
+}
+
+int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s) {
+  DRM_REQUIRE(a.ksplit > 1 && a.split_stride % 4 == 0 && a.Cout % 4 == 0, "split-K reduction arguments");
+  const int HW = a.H * a.W;
+  const int ppb = 32;  // pixels per block: deep maps are 16 .. 512 pixels per image
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((HW + ppb - 1) / ppb, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),
+                     a.split_stride / 4, a.ksplit, a.bias, a.emb, a.emb_stride, a.res, reinterpret_cast<float4*>(a.out),
+                     a.stat_out, HW, a.Cout, ppb);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
 }
 
 int launch_conv_split2(const ConvArgs& a, hipStream_t s) {

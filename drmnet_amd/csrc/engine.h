@@ -146,7 +146,9 @@ int run_resblock(Ctx& c, const float* wbuf, const ResLayer& r, Act& x0, Act* x1,
 int run_attention(Ctx& c, const float* wbuf, const AttnLayer& a, Act& x, Act& out);
 // dispatches to the fp32 or the split-precision conv kernel; scale_off = the conv's pre-scaling slot in wbuf
 // `stats_for` (optional): the activation this conv completes -- its GroupNorm statistics are then accumulated in the epilogue
-int run_conv(Ctx& c, ConvArgs& a, const float* wbuf, size_t scale_off, Act* stats_for = nullptr);
+// `splitk_ws`: the partial-slab workspace plan_splitk returned for this launch (null = no split-K)
+int run_conv(Ctx& c, ConvArgs& a, const float* wbuf, size_t scale_off, Act* stats_for = nullptr, float* splitk_ws = nullptr);
+float* plan_splitk(Ctx& c, ConvArgs& a);  // sets a.ksplit / a.split_stride from the shape fields of `a`; allocates the slabs
 // split-precision range guard for an un-normalised conv input (see engine.hip)
 int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab);
 // ensure_moments on both sources + gn_finalize into (scale, shift)

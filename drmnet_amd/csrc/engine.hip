@@ -287,17 +287,43 @@ int ensure_moments(Ctx& c, Act& a) {
   return DRM_OK;
 }
 
-int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_for) {
+// split-K factor the launch will use and the partial-slab workspace it then needs (allocated in sizing and real passes alike)
+float* plan_splitk(Ctx& c, ConvArgs& a) {
+  a.ksplit = 1;
+  if (!(c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0)) return nullptr;
+  a.ksplit = conv_split_ksplit(a);
+  if (a.ksplit <= 1) return nullptr;
+  a.split_stride = (size_t)a.N * a.H * a.W * a.Cout;
+  return c.ar->alloc<float>(a.split_stride * a.ksplit);
+}
+
+int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_for, float* splitk_ws) {
   if (c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0) {
     a.w_inv_scale = Wb + scale_off + 1;
     a.terms = c.terms();
-    a.ksplit = conv_split_ksplit(a);  // deep levels: split the reduction over workgroups (no fused statistics then)
-    if (stats_for && !a.out_nchw && conv_split_fuses_stats() && a.ksplit == 1) {
+    if (!splitk_ws) {
+      a.ksplit = 1;
+      a.split_stride = 0;
+    }
+    double2* stat = nullptr;
+    if (stats_for && !a.out_nchw && conv_split_fuses_stats()) {
       if (!stats_for->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(stats_for->mom, 0, (size_t)c.N * stats_for->C * sizeof(double2), c.s));
-      a.stat_out = stats_for->mom;
+      stat = stats_for->mom;
       stats_for->mom_valid = true;
       stats_for->mom_sums = true;
     }
+    if (a.ksplit > 1) {
+      // deep levels: the reduction is split over workgroups; every split writes its own slab, a fixed-order pass sums them and
+      // applies bias / emb / residual / statistics (deterministic: no atomics on the data path)
+      ConvArgs part = a;
+      part.out = splitk_ws;
+      part.bias = nullptr; part.emb = nullptr; part.res = nullptr; part.stat_out = nullptr;
+      DRM_TRY(launch_conv_split(part, c.s));
+      ConvArgs red = a;
+      red.stat_out = stat;
+      return launch_splitk_reduce(red, splitk_ws, c.s);
+    }
+    a.stat_out = stat;
     return launch_conv_split(a, c.s);
   }
   return launch_conv(a, c.s);
@@ -359,17 +385,21 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
   float* sh2 = c.ar->alloc<float>((size_t)c.N * r.cout);
   ConvArgs k;  // skip_connection: 1x1 conv on the raw (un-normalised) block input; its range-guard tables come out of the same launch
   DRM_TRY(gn_params(c, x0, x1, Wb + r.n1_w, Wb + r.n1_b, sc1, sh1, r.has_skip ? &k : nullptr));
+  ConvArgs a;  // in_layers conv: GroupNorm(x0 | x1) -> SiLU -> 3x3 + emb
+  a.src0 = x0.p; a.src1 = x1 ? x1->p : nullptr; a.C0 = C0; a.C1 = C1; a.up0 = x0.up;
+  a.N = c.N; a.H = H; a.W = W; a.taps = 9; a.Cout = r.cout;
+  float* ws1 = plan_splitk(c, a);
   if (!c.dry()) {
-    ConvArgs a;
-    a.src0 = x0.p; a.src1 = x1 ? x1->p : nullptr; a.C0 = C0; a.C1 = C1; a.up0 = x0.up;
-    a.N = c.N; a.H = H; a.W = W;
     a.gn_scale = sc1; a.gn_shift = sh1; a.silu = 1;
-    a.w = Wb + r.c1_w; a.bias = Wb + r.c1_b; a.taps = 9; a.Cout = r.cout;
+    a.w = Wb + r.c1_w; a.bias = Wb + r.c1_b;
     a.emb = emb_all ? emb_all + r.emb_off : nullptr; a.emb_stride = emb_stride;
     a.out = h1.p;
-    DRM_TRY(run_conv(c, a, Wb, r.c1_s, &h1));
+    DRM_TRY(run_conv(c, a, Wb, r.c1_s, &h1, ws1));
   }
   DRM_TRY(gn_params(c, h1, nullptr, Wb + r.n2_w, Wb + r.n2_b, sc2, sh2));
+  ConvArgs b;  // out_layers conv: GroupNorm(h1) -> SiLU -> 3x3 + residual
+  b.src0 = h1.p; b.C0 = r.cout; b.N = c.N; b.H = H; b.W = W; b.taps = 9; b.Cout = r.cout;
+  float* ws2 = plan_splitk(c, b);
   if (!c.dry()) {
     const float* res = x0.p;
     if (r.has_skip) {
@@ -380,12 +410,10 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
       DRM_TRY(run_conv(c, k, Wb, r.sk_s));
       res = out.p;
     }
-    ConvArgs b;
-    b.src0 = h1.p; b.C0 = r.cout; b.N = c.N; b.H = H; b.W = W;
     b.gn_scale = sc2; b.gn_shift = sh2; b.silu = 1;
-    b.w = Wb + r.c2_w; b.bias = Wb + r.c2_b; b.taps = 9; b.Cout = r.cout;
+    b.w = Wb + r.c2_w; b.bias = Wb + r.c2_b;
     b.res = res; b.out = out.p;
-    DRM_TRY(run_conv(c, b, Wb, r.c2_s, &out));
+    DRM_TRY(run_conv(c, b, Wb, r.c2_s, &out, ws2));
   }
   c.ar->release(mark);
   return DRM_OK;
