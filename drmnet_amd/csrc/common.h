@@ -148,7 +148,8 @@ int launch_hdr2ldr(const float* x, const unsigned char* mask, int HW, float alph
 // absmax_bits (optional): [N] words, zeroed by the caller; receives max |element| per packed image as fp32 bits
 int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s,
                       unsigned* absmax_bits = nullptr);
-int launch_avgpool2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
+// stat (optional, zeroed): [N][C] (sum, sum of squares) of the pooled tensor, accumulated with fp64 atomics
+int launch_avgpool2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s, double2* stat = nullptr);
 int launch_linear(const float* in, const float* w, const float* b, float* out, int N, int I, int O, int silu_in, int silu_out, hipStream_t s);
 int launch_timestep_embedding(const int64_t* t, const float* tf, float* out, int N, int dim, hipStream_t s);
 int launch_encoder_head(const float* x, const float* scale, const float* shift, const float* w, const float* b, float* out, int N, int HW,

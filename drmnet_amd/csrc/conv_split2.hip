@@ -861,16 +861,20 @@ int conv_split_ksplit(const ConvArgs& a) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ partial, size_t slab_f4, int ks, const float* __restrict__ bias,
                                                             const float* __restrict__ emb, int emb_stride, const float* __restrict__ res,
                                                             float4* __restrict__ out, double2* __restrict__ stat, int HW, int Cout, int px_per_block) {
+  __shared__ float red[256][8];
   const int n = blockIdx.y, q4 = Cout >> 2;
   const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, HW);
-  for (int q = threadIdx.x % 64; q < q4; q += 64) {  // 64 channel quads x 4 pixel lanes per pass
-    float4 b = bias ? reinterpret_cast<const float4*>(bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (emb) {
+  const int ql = threadIdx.x % 64, pl = threadIdx.x / 64;
+  for (int q0 = 0; q0 < q4; q0 += 64) {  // 64 channel quads x 4 pixel lanes per pass (every thread runs every pass: barriers below)
+    const int q = q0 + ql;
+    if (q >= q4 && !stat) continue;
+    float4 b = (bias && q < q4) ? reinterpret_cast<const float4*>(bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (emb && q < q4) {
       const float4 e = *reinterpret_cast<const float4*>(emb + (size_t)n * emb_stride + 4 * q);
       b.x += e.x; b.y += e.y; b.z += e.z; b.w += e.w;
     }
     float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int p = p0 + threadIdx.x / 64; p < p1; p += 4) {
+    for (int p = p0 + pl; p < p1 && q < q4; p += 4) {
       const size_t idx = ((size_t)n * HW + p) * q4 + q;
       float4 acc = partial[idx];
       for (int k = 1; k < ks; ++k) {
@@ -886,13 +890,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
       s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
       ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
     }
-    if (stat) {
+    if (stat) {  // fold the 4 pixel lanes of a channel quad in LDS (fixed order), then one fp64 atomic per (block, channel, moment)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        double* d = reinterpret_cast<double*>(stat + (size_t)n * Cout + 4 * q + k);
-        atomicAdd(d, (double)s[k]);
-        atomicAdd(d + 1, (double)ss[k]);
+        red[threadIdx.x][k] = s[k];
+        red[threadIdx.x][4 + k] = ss[k];
       }
+      __syncthreads();
+      if (pl == 0 && q < q4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double a = 0.0, c2 = 0.0;
+          for (int j = 0; j < 4; ++j) {
+            a += (double)red[j * 64 + ql][k];
+            c2 += (double)red[j * 64 + ql][4 + k];
+          }
+          double* d = reinterpret_cast<double*>(stat + (size_t)n * Cout + 4 * q + k);
+          atomicAdd(d, a);
+          atomicAdd(d + 1, c2);
+        }
+      }
+      __syncthreads();
     }
   }
 }
@@ -900,7 +918,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
 int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s) {
   DRM_REQUIRE(a.ksplit > 1 && a.split_stride % 4 == 0 && a.Cout % 4 == 0, "split-K reduction arguments");
   const int HW = a.H * a.W;
-  const int ppb = 32;  // pixels per block: deep maps are 16 .. 512 pixels per image
+  const int ppb = 64;  // pixels per block: deep maps are 16 .. 512 pixels per image
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((HW + ppb - 1) / ppb, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),
                      a.split_stride / 4, a.ksplit, a.bias, a.emb, a.emb_stride, a.res, reinterpret_cast<float4*>(a.out),
                      a.stat_out, HW, a.Cout, ppb);

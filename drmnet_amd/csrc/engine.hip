@@ -550,7 +550,12 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
       } else if (l.kind == Layer::DOWN) {
         DRM_REQUIRE(!h->up, "downsample of an upsampled tensor");
         Act* o = make(h->C, h->H / 2, h->W / 2);
-        if (!c.dry()) DRM_TRY(launch_avgpool2(h->p, o->p, N, h->H, h->W, h->C, s));
+        if (!c.dry()) {
+          if (!o->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(o->mom, 0, (size_t)N * o->C * sizeof(double2), s));
+          DRM_TRY(launch_avgpool2(h->p, o->p, N, h->H, h->W, h->C, s, o->mom));  // pooled tensor + its GroupNorm sums in one pass
+          o->mom_valid = true;
+          o->mom_sums = true;
+        }
         h = o;
       } else {  // UP: nearest x2, folded into the consumer (moments are unchanged by replication)
         DRM_REQUIRE(!h->up, "double upsample");

@@ -12,35 +12,38 @@ __device__ __forceinline__ float silu_m(float v) { return v / (1.0f + __expf(-v)
 // idx (optional) gathers rows: out row j reads sample idx[j] (DRMNet active-set compaction,
 // models/drmnet.py:810-813).
 // ---------------------------------------------------------------------------------------------
-// One thread per (pixel, 4-channel quad): the NHWC writes are fully coalesced 16-byte stores; only the first
-// (Cx + Cc + 3) / 4 quads read anything.
+// One thread per pixel: the NCHW reads are coalesced along the pixel axis in every channel plane (the previous (pixel, quad)
+// mapping read 32-byte fragments: 216 us per launch at B = 32, 3x128x256), the NHWC row of CP floats is written as whole float4s.
 // grid (blocks over one image, N): a block never straddles two images, so the optional per-image absmax is a block reduction and
 // at most ONE atomicMax per block (non-negative floats order like their bit patterns) -- skipped when the word already holds a
 // value at least as large (a stale read only costs a redundant atomic; same-address atomics serialise at the memory side).
+template <int Q>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ cond, const int* __restrict__ idx,
-                                                          float4* __restrict__ out, int N, int HW, int Cx, int Cc, int Q,
-                                                          unsigned* __restrict__ absmax_bits) {
+                                                          float4* __restrict__ out, int HW, int Cx, int Cc, unsigned* __restrict__ absmax_bits) {
   const int n = blockIdx.y;
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, quad) inside image n
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool live = j < (long long)HW * Q;
-  const int q = (int)(j % Q);
-  const int p = (int)(j / Q);
-  const long long i = (long long)n * HW * Q + j;
-  if (live && 4 * q < Cx + Cc) {
-    const int src = idx ? idx[n] : n;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < HW;
+  const int src = idx ? idx[n] : n;
+  float v[4 * Q];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = 4 * q + k;
-      if (c < Cx) v[k] = x[((size_t)src * Cx + c) * HW + p];
-      else if (c < Cx + Cc) v[k] = cond[((size_t)src * Cc + (c - Cx)) * HW + p];
+  for (int c = 0; c < 4 * Q; ++c) {
+    float t = 0.f;
+    if (live) {
+      if (c < Cx) t = x[((size_t)src * Cx + c) * HW + p];
+      else if (c < Cx + Cc) t = cond[((size_t)src * Cc + (c - Cx)) * HW + p];
     }
+    v[c] = t;
   }
-  if (live) out[i] = make_float4(v[0], v[1], v[2], v[3]);
+  if (live) {
+    float4* o = out + ((size_t)n * HW + p) * Q;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
   if (absmax_bits) {
     __shared__ float wmax[4];
-    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    if (!(m == m)) m = INFINITY;  // NaN input: no finite bound
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4 * Q; ++c) m = fmaxf(m, fabsf(v[c]) == fabsf(v[c]) ? fabsf(v[c]) : INFINITY);  // NaN input: no finite bound
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
@@ -53,43 +56,101 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
   }
 }
 
+// any padded width (per-module test entry points with wide inputs): one thread per (pixel, 4-channel quad)
+__global__ __launch_bounds__(256) void pack_input_generic_kernel(const float* __restrict__ x, const float* __restrict__ cond,
+                                                                  const int* __restrict__ idx, float4* __restrict__ out, int HW, int Cx, int Cc, int Q) {
+  const int n = blockIdx.y;
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= (long long)HW * Q) return;
+  const int q = (int)(j % Q), p = (int)(j / Q);
+  const int src = idx ? idx[n] : n;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * q + k;
+    if (c < Cx) v[k] = x[((size_t)src * Cx + c) * HW + p];
+    else if (c < Cx + Cc) v[k] = cond[((size_t)src * Cc + (c - Cx)) * HW + p];
+  }
+  out[(size_t)n * HW * Q + j] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s,
                       unsigned* absmax_bits) {
-  DRM_REQUIRE(CP % 4 == 0, "packed input channels must be a multiple of 4");
-  const long long per_image = (long long)H * W * (CP / 4);
-  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((per_image + 255) / 256), (unsigned)N), dim3(256), 0, s, x, cond, idx,
-                     reinterpret_cast<float4*>(out), N, H * W, Cx, Cc, CP / 4, absmax_bits);
+  DRM_REQUIRE(CP % 4 == 0 && CP >= Cx + Cc, "packed input channels must be a multiple of 4 that holds x and cond");
+  const int HW = H * W;
+  const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)N), block(256);
+  float4* o = reinterpret_cast<float4*>(out);
+  switch (CP / 4) {
+    case 1: hipLaunchKernelGGL(pack_input_kernel<1>, grid, block, 0, s, x, cond, idx, o, HW, Cx, Cc, absmax_bits); break;
+    case 2: hipLaunchKernelGGL(pack_input_kernel<2>, grid, block, 0, s, x, cond, idx, o, HW, Cx, Cc, absmax_bits); break;
+    case 8: hipLaunchKernelGGL(pack_input_kernel<8>, grid, block, 0, s, x, cond, idx, o, HW, Cx, Cc, absmax_bits); break;
+    default:
+      DRM_REQUIRE(!absmax_bits, "packed input: the absmax output needs a 4-, 8- or 32-channel padding");
+      hipLaunchKernelGGL(pack_input_generic_kernel, dim3((unsigned)(((long long)HW * (CP / 4) + 255) / 256), (unsigned)N), block, 0, s, x, cond, idx, o,
+                         HW, Cx, Cc, CP / 4);
+  }
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }
 
-// Downsample without conv = AvgPool2d(2,2) (openaimodel.py:154-160), NHWC
-__global__ void avgpool2_kernel(const float4* __restrict__ x, float4* __restrict__ out, int N, int Ho, int Wo, int q4) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)N * Ho * Wo * q4;
-  if (i >= total) return;
-  const int q = (int)(i % q4);
-  long long t = i / q4;
-  const int xo = (int)(t % Wo);
-  t /= Wo;
-  const int yo = (int)(t % Ho);
-  const int n = (int)(t / Ho);
-  const int W = Wo * 2;
-  const size_t base = (((size_t)n * Ho * 2 + yo * 2) * W + xo * 2) * q4 + q;
-  const float4 a = x[base], b = x[base + q4], c = x[base + (size_t)W * q4], d = x[base + (size_t)W * q4 + q4];
-  float4 r;
-  r.x = (a.x + b.x + c.x + d.x) * 0.25f;
-  r.y = (a.y + b.y + c.y + d.y) * 0.25f;
-  r.z = (a.z + b.z + c.z + d.z) * 0.25f;
-  r.w = (a.w + b.w + c.w + d.w) * 0.25f;
-  out[i] = r;
+// Downsample without conv = AvgPool2d(2,2) (openaimodel.py:154-160), NHWC, fused with the per-(image, channel) sums / sums of
+// squares of its OUTPUT (the next block's GroupNorm statistics: no stand-alone moments pass over the pooled tensor).
+// grid (pixel blocks, N), block 256 = QL channel-quad lanes x PL pixel lanes; a thread walks its pixels with fp32 partial sums and
+// ends with one fp64 atomic per (channel, moment).
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float4* __restrict__ x, float4* __restrict__ out, double2* __restrict__ stat, int Ho, int Wo,
+                                                       int q4, int QL, int px_per_block) {
+  __shared__ float red[256][8];  // per-thread partial (4 sums, 4 sums of squares): the pixel lanes of a channel quad are folded here
+  const int n = blockIdx.y;
+  const int ql = threadIdx.x % QL, pl = threadIdx.x / QL, PL = 256 / QL;
+  const int HWo = Ho * Wo, W = Wo * 2;
+  const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, HWo);
+  for (int q0 = 0; q0 < q4; q0 += QL) {  // (every thread runs every pass: the statistics fold has barriers)
+    const int q = q0 + ql;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + pl; p < p1 && q < q4; p += PL) {
+      const int yo = p / Wo, xo = p % Wo;
+      const size_t base = (((size_t)n * Ho * 2 + yo * 2) * W + xo * 2) * q4 + q;
+      const float4 a = x[base], b = x[base + q4], c = x[base + (size_t)W * q4], d = x[base + (size_t)W * q4 + q4];
+      float4 r;
+      r.x = (a.x + b.x + c.x + d.x) * 0.25f;
+      r.y = (a.y + b.y + c.y + d.y) * 0.25f;
+      r.z = (a.z + b.z + c.z + d.z) * 0.25f;
+      r.w = (a.w + b.w + c.w + d.w) * 0.25f;
+      out[((size_t)n * HWo + p) * q4 + q] = r;
+      s[0] += r.x; s[1] += r.y; s[2] += r.z; s[3] += r.w;
+      ss[0] += r.x * r.x; ss[1] += r.y * r.y; ss[2] += r.z * r.z; ss[3] += r.w * r.w;
+    }
+    if (stat) {  // (uniform per block: every thread reaches the barriers)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[threadIdx.x][k] = s[k];
+        red[threadIdx.x][4 + k] = ss[k];
+      }
+      __syncthreads();
+      if (pl == 0 && q < q4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double a = 0.0, b = 0.0;
+          for (int j = 0; j < PL; ++j) {  // fixed order
+            a += (double)red[j * QL + ql][k];
+            b += (double)red[j * QL + ql][4 + k];
+          }
+          double* dd = reinterpret_cast<double*>(stat + (size_t)n * q4 * 4 + 4 * q + k);
+          atomicAdd(dd, a);
+          atomicAdd(dd + 1, b);
+        }
+      }
+      __syncthreads();
+    }
+  }
 }
 
-int launch_avgpool2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s) {
+int launch_avgpool2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s, double2* stat) {
   DRM_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "avgpool2 shape");
-  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
-                     reinterpret_cast<float4*>(out), N, H / 2, W / 2, C / 4);
+  const int q4 = C / 4, QL = q4 >= 64 ? 64 : (q4 >= 32 ? 32 : (q4 >= 16 ? 16 : (q4 >= 8 ? 8 : 4)));
+  const int HWo = (H / 2) * (W / 2), ppb = 256;  // one fp64 atomic per (256-pixel block, channel, moment)
+  hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)((HWo + ppb - 1) / ppb), (unsigned)N), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<float4*>(out), stat, H / 2, W / 2, q4, QL, ppb);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }
