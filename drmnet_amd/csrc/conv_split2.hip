@@ -75,10 +75,17 @@ struct S2Cfg {
   static constexpr int WTP = PAD_FITS ? WTP_TRY : WT;  // stored row stride (pixels)
   static constexpr int HPIP = HT * WTP;                // stored pixels per image
   static constexpr int HP = TN * HPIP;
+  // Plane stride of the [hi|lo][slab][lane half] planes, padded to 2 (mod 8) pixels: the staging ds_write_b128s of a lane group
+  // go to the four octet planes of two neighbouring pixels, and with an unpadded stride that is a multiple of 128 bytes
+  // (18 x 24 pixels x 16 B) the four planes fell on the same banks (SQ_LDS_BANK_CONFLICT: 17 % of the LDS cycles of a launch).  The
+  // fragment reads of one ds_read_b128 lane group stay inside one plane, so their conflict-free pattern is unchanged.
+  static constexpr int HPS_TRY = HP + ((2 - HP % 8) + 8) % 8;
   static constexpr int TPI = NTHR / TN;  // loader threads per image
   static constexpr int OCT = 4;
   static constexpr int A_SLOTS = (HPI * OCT + TPI - 1) / TPI;
-  static constexpr int A1_F4 = 8 * HP;                       // one activation tile image
+  static constexpr bool HPS_FITS = ((TAPS == 1 ? 2 : 1) * 8 * HPS_TRY + R * TPS * 8 * (WN * NT * 32) + TN * (WN * NT * 32)) * 16 <= 160 * 1024;
+  static constexpr int HPS = HPS_FITS ? HPS_TRY : HP;
+  static constexpr int A1_F4 = 8 * HPS;                      // one activation tile image
   static constexpr int A_F4 = A_COPIES * A1_F4;  // 1x1: double-buffered (a new tile every step)
   static constexpr int B_F4 = 8 * BN;                            // LDS image of one tap's weight tile (hi and lo planes)
   static constexpr int B_DMA_F4 = (TERMS == 3 ? 8 : 4) * BN;      // what is fetched: the single-product mode needs the hi plane only
@@ -324,8 +331,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         }
         const int hpl = lidx / C::OCT;
         const int pixel = l_img * C::HPIP + (hpl / C::WT) * C::WTP + (hpl % C::WT);
-        Ad[l_o * C::HP + pixel] = hi.f4;
-        if (TERMS == 3) Ad[(4 + l_o) * C::HP + pixel] = lo.f4;
+        Ad[l_o * C::HPS + pixel] = hi.f4;
+        if (TERMS == 3) Ad[(4 + l_o) * C::HPS + pixel] = lo.f4;
       }
     }
   };
@@ -455,8 +462,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         F4H8b ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          ah[i].f4 = Ab[seg * C::HP + a_base[i] + tapoff];
-          if (TERMS == 3) al[i].f4 = Ab[(4 + seg) * C::HP + a_base[i] + tapoff];
+          ah[i].f4 = Ab[seg * C::HPS + a_base[i] + tapoff];
+          if (TERMS == 3) al[i].f4 = Ab[(4 + seg) * C::HPS + a_base[i] + tapoff];
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
