@@ -881,6 +881,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
       b.x += e.x; b.y += e.y; b.z += e.z; b.w += e.w;
     }
     float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4  // (independent pixels: lets the loads of four iterations be in flight together -- the loop is latency-bound)
     for (int p = p0 + pl; p < p1 && q < q4; p += 4) {
       const size_t idx = ((size_t)n * HW + p) * q4 + q;
       float4 acc = partial[idx];
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
 int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s) {
   DRM_REQUIRE(a.ksplit > 1 && a.split_stride % 4 == 0 && a.Cout % 4 == 0, "split-K reduction arguments");
   const int HW = a.H * a.W;
-  const int ppb = 64;  // pixels per block: deep maps are 16 .. 512 pixels per image
+  const int ppb = 64;  // pixels per block: 16 per pixel lane (more blocks = more same-address statistics atomics: measured slower at B = 1)
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((HW + ppb - 1) / ppb, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),
                      a.split_stride / 4, a.ksplit, a.bias, a.emb, a.emb_stride, a.res, reinterpret_cast<float4*>(a.out),
                      a.stat_out, HW, a.Cout, ppb);

@@ -193,7 +193,12 @@ class _HipUNetBase(nn.Module):
         return self._h
 
     def workspace_bytes(self, n: int, h: int, w: int) -> int:
-        return int(_lib.lib().drm_unet_workspace_bytes(self._h, n, h, w))
+        """Arena size of one forward (a sizing pass of the whole schedule inside the library): memoised per (shape, precision)."""
+        key = (n, h, w, self.precision)
+        cache = self.__dict__.setdefault("_ws_bytes", {})
+        if key not in cache:
+            cache[key] = int(_lib.lib().drm_unet_workspace_bytes(self._h, n, h, w))
+        return cache[key]
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -225,8 +230,7 @@ class _HipUNetBase(nn.Module):
             rows = _lib.require_gpu_tensor(rows, "rows", torch.int32)
         self.sync_weights()
         L = _lib.lib()
-        need = int(L.drm_unet_workspace_bytes(self._h, n, hh, ww))
-        ws = self._ws.get(need, dev)
+        ws = self._ws.get(self.workspace_bytes(n, hh, ww), dev)
         if self._kind == 0:
             out = torch.empty((n, self.out_channels, hh, ww), dtype=torch.float32, device=dev)
         else:
