@@ -81,7 +81,7 @@ struct ConvArgs {
   size_t split_stride = 0;             // floats between the split-K slabs (0 unless ksplit > 1)
   int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 1 = plain fp16 operands
 #ifdef DRM_S2_STAMP
-  unsigned* stamp_out = nullptr;       // diagnostic build: [8 waves][128][2] (id, s_memtime low word) of one workgroup
+  unsigned* stamp_out = nullptr;       // diagnostic build: [8 waves][120][2] (id, s_memtime low word) of one workgroup
   int stamp_block = 0, stamp_tile0 = 0;
 #endif
   double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)

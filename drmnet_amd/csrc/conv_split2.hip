@@ -27,19 +27,19 @@
 #include "profiler.h"
 
 // Diagnostic build only (tools/stamp_probe.sh, -DDRM_S2_STAMP, a separate .so): one workgroup records an s_memtime timeline of
-// its waves (cdna_hip_programming.md 7 "In-kernel stamps") into the 8 KiB of LDS the main 3x3 variant leaves free; it leaves the
+// its waves (cdna_hip_programming.md 7 "In-kernel stamps") into the 7.5 KiB of LDS the main 3x3 variant leaves free; it leaves the
 // kernel through a buffer nothing else reads.  The product library compiles every S2_STAMP to nothing.
 #ifdef DRM_S2_STAMP
 #define S2_STAMP(id)                                                                               \
   do {                                                                                             \
-    if (stamp_on && stamp_n < 128) {                                                               \
+    if (stamp_on && stamp_n < 120) {                                                               \
       unsigned long long t_;                                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                           \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
       __builtin_amdgcn_sched_barrier(0);                                                           \
       if (lane == 0) {                                                                             \
-        stamp_lds[(wave * 128 + stamp_n) * 2] = (unsigned)(id);                                    \
-        stamp_lds[(wave * 128 + stamp_n) * 2 + 1] = (unsigned)t_;                                  \
+        stamp_lds[(wave * 120 + stamp_n) * 2] = (unsigned)(id);                                    \
+        stamp_lds[(wave * 120 + stamp_n) * 2 + 1] = (unsigned)t_;                                  \
       }                                                                                            \
       ++stamp_n;                                                                                   \
     }                                                                                              \
@@ -232,12 +232,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   if (k_tile >= x_count) return;
   TilePos cur = decode(x_start + k_tile);
 #ifdef DRM_S2_STAMP
-  unsigned* stamp_lds = reinterpret_cast<unsigned*>(lds + C::LDS_F4);  // [NW][128][2]
+  unsigned* stamp_lds = reinterpret_cast<unsigned*>(lds + C::LDS_F4);  // [NW][120][2]
   int stamp_n = 0;
   int stamp_tiles = 0;
   bool stamp_on = false;
-  if (a.stamp_out && (int)blockIdx.x == a.stamp_block)
-    for (int k = tid; k < C::NW * 256; k += C::NTHR) stamp_lds[k] = 0;
+  if (a.stamp_out && (int)blockIdx.x == (a.stamp_block & 0xFFFF))
+    for (int k = tid; k < C::NW * 240; k += C::NTHR) stamp_lds[k] = 0;
 #endif
 
   const int Ctot = a.C0 + a.C1;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     const bool has_next = k_tile + J < x_count;
     const TilePos nxt = has_next ? decode(x_start + k_tile + J) : cur;
 #ifdef DRM_S2_STAMP
-    stamp_on = a.stamp_out && (int)blockIdx.x == a.stamp_block && stamp_tiles >= a.stamp_tile0;
+    stamp_on = a.stamp_out && (int)blockIdx.x == (a.stamp_block & 0xFFFF) && stamp_tiles >= a.stamp_tile0;
     ++stamp_tiles;
     S2_STAMP(1);  // tile start
 #endif
@@ -617,6 +617,24 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     }
 
     S2_STAMP(9);  // epilogue start
+#ifdef DRM_S2_STAMP
+    // timing experiments of the diagnostic build (tools/epi_cost.sh): stamp_block bit 16 = no output stores, bit 17 = no epilogue at all
+    const bool skip_epilogue = a.stamp_block & 0x20000;
+    if (skip_epilogue) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            t += acc[i][c][e];
+            acc[i][c][e] = 0.f;
+          }
+      if (t == 12345.678f) out_s[0] = t;  // keeps the accumulators alive
+    }
+    if (!skip_epilogue)
+#endif
     // ---- epilogue of the current tile.  Rows of a 32x32 accumulator tile held by this lane: 8g + 4h + k (g, k = 0..3);
     // the four k rows are four consecutive pixels of one image row (TW % 4 == 0), so addresses are formed once per
     // (i, g).  Loads are issued unconditionally on clamped addresses (batched ahead of the math); stores are predicated
@@ -641,6 +659,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       for (int c = 0; c < NT; ++c) {
         const int col = (wn * NT + c) * 32 + r;
         const int co = cur.co0 + col;
+        S2_STAMP(20 + 4 * (i * NT + c));  // block (i, c) of the epilogue starts
         // split-K: every split writes its raw partial sums to its own slab (a.out + split * slab); bias / emb / residual and the
         // statistics are applied by the fixed-order reduction that follows (splitk_reduce_kernel)
         const bool first = ks == 1;
@@ -676,6 +695,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             }
           }
         }
+        S2_STAMP(21 + 4 * (i * NT + c));  // values ready (bias / emb / residual landed and applied, statistics partials)
         if (a.out_nchw) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -694,9 +714,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], r);
+#ifdef DRM_S2_STAMP
+            if (a.stamp_block & 0x10000) {
+              if (v[4 * g] == 12345.678f) out_s[0] = v[4 * g + 1] + v[4 * g + 2] + v[4 * g + 3];
+              continue;
+            }
+#endif
             if (okg[g]) *reinterpret_cast<float4*>(&out_s[(pixb[g] + (r & 3)) * a.Cout + cq]) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
           }
         }
+        S2_STAMP(22 + 4 * (i * NT + c));  // stores issued
         if (st) {
           const int row0 = (wm * MT + i) * 32;
           if (PPI >= 32) {
@@ -712,6 +739,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             atomicAdd(d2 + 1, (double)q1);
           }
         }
+        S2_STAMP(23 + 4 * (i * NT + c));  // statistics atomics issued
       }
     }
     if (st) {
@@ -734,10 +762,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   }
   wait_vmcnt<0>();  // drain the tail DMAs before the workgroup's LDS can be re-assigned
 #ifdef DRM_S2_STAMP
-  if (a.stamp_out && (int)blockIdx.x == a.stamp_block) {
+  if (a.stamp_out && (int)blockIdx.x == (a.stamp_block & 0xFFFF)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int k = tid; k < C::NW * 256; k += C::NTHR) a.stamp_out[k] = stamp_lds[k];
+    for (int k = tid; k < C::NW * 240; k += C::NTHR) a.stamp_out[k] = stamp_lds[k];
   }
 #endif
 }
@@ -777,9 +805,9 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
                  4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);
 #ifdef DRM_S2_STAMP
     // DRM_S2_STAMP_FILE=<path> [DRM_S2_STAMP_BLOCK=<workgroup>] [DRM_S2_STAMP_TILE0=<first recorded tile>]: appends one record
-    // per 8-wave launch that has the 8 KiB of LDS to spare
+    // per 8-wave launch that has the 7.5 KiB of LDS to spare
     static const char* stamp_file = getenv("DRM_S2_STAMP_FILE");
-    if (stamp_file && C::NW == 8 && lds_bytes + 8192 <= di->lds_per_cu) {
+    if (stamp_file && C::NW == 8 && lds_bytes + 7680 <= di->lds_per_cu) {
       static unsigned* dbuf = nullptr;
       if (!dbuf) DRM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 8192));
       DRM_HIP_CHECK(hipMemsetAsync(dbuf, 0, 8192, s));
@@ -787,8 +815,8 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
       at.stamp_out = dbuf;
       at.stamp_block = getenv("DRM_S2_STAMP_BLOCK") ? atoi(getenv("DRM_S2_STAMP_BLOCK")) : 8;
       at.stamp_tile0 = getenv("DRM_S2_STAMP_TILE0") ? atoi(getenv("DRM_S2_STAMP_TILE0")) : 2;
-      DRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes + 8192));
-      hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes + 8192, s, at);
+      DRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes + 7680));
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes + 7680, s, at);
       DRM_HIP_CHECK(hipStreamSynchronize(s));
       std::vector<unsigned> h(2048);
       DRM_HIP_CHECK(hipMemcpy(h.data(), dbuf, 8192, hipMemcpyDeviceToHost));
@@ -796,11 +824,15 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
         fprintf(f, "launch taps %d tile %dx%d C %d->%d map %dx%d N %d grid %lld\n", TAPS, TH, TW, a.C0 + a.C1, a.Cout, a.H, a.W, a.N, grid);
         for (int w = 0; w < 8; ++w) {
           fprintf(f, "wave %d:", w);
-          for (int k = 0; k < 128 && h[(w * 128 + k) * 2]; ++k) fprintf(f, " %u:%u", h[(w * 128 + k) * 2], h[(w * 128 + k) * 2 + 1]);
+          for (int k = 0; k < 120 && h[(w * 120 + k) * 2]; ++k) fprintf(f, " %u:%u", h[(w * 120 + k) * 2], h[(w * 120 + k) * 2 + 1]);
           fprintf(f, "\n");
         }
         fclose(f);
       }
+    } else if (static const char* fl = getenv("DRM_S2_FLAGS"); fl) {  // timing experiments without a timeline: 65536 no output stores, 131072 no epilogue
+      ConvArgs at = a;
+      at.stamp_block = atoi(fl) & ~0xFFFF;
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes, s, at);
     } else
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes, s, a);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reads the timeline written by tools/stamp_probe.sh: per launch, where one workgroup's waves spend their cycles.
-Stamp ids: 1 tile start, 2 step start, 3 step's MFMAs/requests issued, 4 chunk-end barrier 1, 5 activation loads landed, 6 staged,
+Stamp ids (epilogue blocks: 20+4b start, 21+4b values ready, 22+4b stores issued, 23+4b statistics issued -- tools/stamp_epi.py): 1 tile start, 2 step start, 3 step's MFMAs/requests issued, 4 chunk-end barrier 1, 5 activation loads landed, 6 staged,
 7 weights landed, 8 barrier passed, 9 epilogue start, 10 tile end."""
 import collections
 import sys
