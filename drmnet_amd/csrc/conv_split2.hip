@@ -470,16 +470,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           bh[c].f4 = Bc[seg * C::BN + b_base[c]];
           if (TERMS == 3) bl[c].f4 = Bc[(4 + seg) * C::BN + b_base[c]];
         }
+        // term-major order: the three products of one accumulator block are MT * NT instructions apart (per block the order of the
+        // additions is unchanged: lo*hi, hi*lo, hi*hi)
+        static_for(std::make_integer_sequence<int, 3>{}, [&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int T0 = (TERMS == 3) ? 0 : 2;  // single-product mode: hi*hi only
+          if constexpr (t >= T0) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int c = 0; c < NT; ++c) {
-            if (TERMS == 3) {
-              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
-            }
-            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-            if (i == 0 && c == 0) {
+              for (int c = 0; c < NT; ++c) {
+                if constexpr (t == 0) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+                if constexpr (t == 1) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
+                if constexpr (t == 2) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+              }
+            if constexpr (t == T0) {
               // memory-side instructions of this step go out here, a few at a time, behind MFMAs that keep the pipe busy
               // while the (blocking) vector-memory issue waits for the CU's address path
               __builtin_amdgcn_sched_barrier(0);
@@ -487,6 +492,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
               __builtin_amdgcn_sched_barrier(0);
             }
           }
+        });
       }
     };
     // group R-1 steps ahead of tile-local group index gi0: inside this tile, else the matching group of the next tile
