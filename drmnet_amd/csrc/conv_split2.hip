@@ -444,6 +444,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   // the phase timers of the experiment build: with every wave doing the same phase at the same time the MFMA pipe sat
   // idle 55 % of the main loop (17 % in DMA issue alone: the CU's texture-address path serialises the 1-KiB DMAs).
   const bool y_first = (C::NW == 8) && (wave >= C::NW / 2);
+  // 3x3: static priority for the second-dispatched wave half, which otherwise loses every issue arbitration by age and arrives last at every
+  // barrier (A/B on one box: 3x3 family -0.6 %; the HBM-bound 1x1 form gets 5.7 % slower with it, so it stays without)
+  if (TAPS == 9 && C::NW == 8 && wave >= C::NW / 2) __builtin_amdgcn_s_setprio(1);
   constexpr int BASE = C::G_PER * (R - 2);
   int step = 0;  // steps executed so far (== gseq - (R-1))
   while (true) {
