@@ -51,4 +51,4 @@ print(open(f'{OUT}/{tag}_bench_f16x3.json').read()[:400])
 for r in rows[:8]: print(r)
 print(json.dumps(list(res["kernels"].items())[:2], indent=0)[:600])
 PY
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
+rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write"
