@@ -228,13 +228,15 @@ class _HipUNetBase(nn.Module):
                 raise RuntimeError(f"t_emb must be [{n}, {self.model_channels}]")
         if rows is not None:
             rows = _lib.require_gpu_tensor(rows, "rows", torch.int32)
-        self.sync_weights()
-        L = _lib.lib()
-        ws = self._ws.get(self.workspace_bytes(n, hh, ww), dev)
         if self._kind == 0:
             out = torch.empty((n, self.out_channels, hh, ww), dtype=torch.float32, device=dev)
         else:
             out = torch.empty((n, self.out_channels), dtype=torch.float32, device=dev)
+        if n == 0:  # an empty batch is an empty result, as in the reference (every row of a DRMNet batch may have converged)
+            return out
+        self.sync_weights()
+        L = _lib.lib()
+        ws = self._ws.get(self.workspace_bytes(n, hh, ww), dev)
         with torch.cuda.device(dev):
             _lib.check(
                 L.drm_unet_forward(self._h, x.data_ptr(), cx, _lib.ptr(cond), cc, _lib.ptr(rows), _lib.ptr(t_emb), _lib.ptr(ti), _lib.ptr(tf),
