@@ -115,7 +115,7 @@ int chan_moments_splits(int HW, int C);
 // inv0 / inv1: factor turning a table into per-pixel means (1 for tables of means, 1/(H*W) for tables of raw sums)
 // per-image power-of-two staging factor for un-normalised inputs of the split-precision convs (gn.hip)
 int launch_act_pow2_scale(const double2* mom0, int C0, int lo0, int hi0, double cnt0, const double2* mom1, int C1, double cnt1,
-                          const unsigned* absmax_bits, int Ctab, int N, float* scale, float* shift, float* inv, hipStream_t s);
+                          const unsigned* absmax_bits, int Ctab, int N, float* scale, float* shift, float* inv, hipStream_t s, int absmax_parts = 1);
 // guard_*: optional fused range-guard tables of the same tensor (act_pow2_scale_kernel's product), cnt0 / cnt1 as there
 int launch_gn_finalize(const double2* mom0, int C0, double inv0, const double2* mom1, int C1, double inv1, const float* gamma,
                        const float* beta, int N, float* scale, float* shift, hipStream_t s, double cnt0 = 0.0, double cnt1 = 0.0,
@@ -145,7 +145,8 @@ int launch_mirmap2envmap(const float* mir, const float* basis, float* out, int B
 int launch_hdr2ldr(const float* x, const unsigned char* mask, int HW, float alpha, float gamma, float* out, hipStream_t s);
 
 // misc kernels (misc.hip)
-// absmax_bits (optional): [N] words, zeroed by the caller; receives max |element| per packed image as fp32 bits
+// absmax_bits (optional): [N][pack_input_absmax_parts(H, W)] words, every one written: max |element| of one block of a packed image as fp32 bits
+int pack_input_absmax_parts(int H, int W);
 int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s,
                       unsigned* absmax_bits = nullptr);
 // stat (optional, zeroed): [N][C] (sum, sum of squares) of the pooled tensor, accumulated with fp64 atomics

@@ -150,7 +150,7 @@ int run_attention(Ctx& c, const float* wbuf, const AttnLayer& a, Act& x, Act& ou
 int run_conv(Ctx& c, ConvArgs& a, const float* wbuf, size_t scale_off, Act* stats_for = nullptr, float* splitk_ws = nullptr);
 float* plan_splitk(Ctx& c, ConvArgs& a);  // sets a.ksplit / a.split_stride from the shape fields of `a`; allocates the slabs
 // split-precision range guard for an un-normalised conv input (see engine.hip)
-int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab);
+int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab, int absmax_parts = 1);
 // ensure_moments on both sources + gn_finalize into (scale, shift)
 // guard_for (optional): a split conv reading (x0 | x1) un-normalised gets its range-guard tables from the same launch
 int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift, ConvArgs* guard_for = nullptr);

@@ -333,7 +333,7 @@ int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_
 // derived from a rigorous bound of max |x| (gn.hip act_pow2_scale_kernel) so nothing saturates or underflows fp16; the factor rides
 // on the (scale, shift) tables the staging path applies anyway and is undone per image in the epilogue.  Bound source: the
 // per-channel sum-of-squares tables of x0 (channels [lo0, hi0)) and x1, or an absmax word per image.  No-op in fp32 mode.
-int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab) {
+int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab, int absmax_parts) {
   if (!c.split() || Ctab % 32 != 0) return DRM_OK;  // (channel counts that are not whole 32-chunks run on the exact-fp32 kernel)
   float* sc = c.ar->alloc<float>((size_t)c.N * Ctab);
   float* sh = c.ar->alloc<float>((size_t)c.N * Ctab);
@@ -343,7 +343,7 @@ int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, con
   if (c.dry()) return DRM_OK;
   auto cnt = [](const Act& t) { return t.mom_sums ? 0.0 : (double)(t.H >> t.up) * (t.W >> t.up); };
   DRM_TRY(launch_act_pow2_scale(x0 ? x0->mom : nullptr, x0 ? x0->C : 0, lo0, hi0, x0 ? cnt(*x0) : 0.0, x1 ? x1->mom : nullptr, x1 ? x1->C : 0,
-                                x1 ? cnt(*x1) : 0.0, absmax_bits, Ctab, c.N, sc, sh, inv, c.s));
+                                x1 ? cnt(*x1) : 0.0, absmax_bits, Ctab, c.N, sc, sh, inv, c.s, absmax_parts));
   a.gn_scale = sc;
   a.gn_shift = sh;
   a.in_inv = inv;
@@ -501,14 +501,13 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   } pool_scope{ar};
 
   Act xin = new_act(c, in_cp, H, W);
-  bool amax_zeroed = false;
-  unsigned* amax = reinterpret_cast<unsigned*>(c.ar->alloc_stats((size_t)N * sizeof(unsigned), &amax_zeroed));  // per-image max |input|
+  const int amax_parts = pack_input_absmax_parts(H, W);
+  unsigned* amax = c.ar->alloc<unsigned>((size_t)N * amax_parts);  // max |input| per (image, pack block): every word is written by the pack kernel
   float* temb = c.ar->alloc<float>((size_t)N * mc);
   float* e1 = c.ar->alloc<float>((size_t)N * emb_dim);
   float* emb = c.ar->alloc<float>((size_t)N * emb_dim);
   float* emb_all = c.ar->alloc<float>((size_t)N * emb_total);
   if (!c.dry()) {
-    if (!amax_zeroed) DRM_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)N * sizeof(unsigned), s));
     DRM_TRY(launch_pack_input(x, cond, rows, xin.p, N, H, W, Cx, Cc, in_cp, s, amax));
     const float* te = t_emb;
     if (!te) {
@@ -528,7 +527,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   std::vector<Act*> hs;
   Act* h = make(mc, H, W);
   ConvArgs a;  // stem conv: raw network input
-  DRM_TRY(raw_input_guard(c, a, nullptr, 0, 0, nullptr, amax, in_cp));
+  DRM_TRY(raw_input_guard(c, a, nullptr, 0, 0, nullptr, amax, in_cp, amax_parts));
   if (!c.dry()) {
     a.src0 = xin.p; a.C0 = in_cp; a.N = N; a.H = H; a.W = W;
     a.w = Wb + stem_w; a.bias = Wb + stem_b; a.taps = 9; a.Cout = mc; a.out = h->p; a.cin_real = desc.in_channels;

@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restr
 // grid N, block 256.  cnt: pixels per table entry when the table holds means instead of raw sums (0 = raw sums).
 __global__ __launch_bounds__(256) void act_pow2_scale_kernel(const double2* __restrict__ mom0, int C0, int lo0, int hi0, double cnt0,
                                                              const double2* __restrict__ mom1, int C1, double cnt1,
-                                                             const unsigned* __restrict__ absmax_bits, int Ctab, float* __restrict__ scale,
-                                                             float* __restrict__ shift, float* __restrict__ inv) {
+                                                             const unsigned* __restrict__ absmax_bits, int absmax_parts, int Ctab,
+                                                             float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ inv) {
   __shared__ double red[4];
   __shared__ float s_scale;
   const int n = blockIdx.x, t = threadIdx.x;
@@ -181,13 +181,17 @@ __global__ __launch_bounds__(256) void act_pow2_scale_kernel(const double2* __re
     for (int c = lo0 + t; c < hi0; c += 256) m = fmax(m, mom0[(size_t)n * C0 + c].y * (cnt0 > 0 ? cnt0 : 1.0));
   if (mom1)
     for (int c = t; c < C1; c += 256) m = fmax(m, mom1[(size_t)n * C1 + c].y * (cnt1 > 0 ? cnt1 : 1.0));
+  if (absmax_bits)  // explicit bounds (one word per producer block): squared, so they fold with the sum-of-squares bounds
+    for (int i = t; i < absmax_parts; i += 256) {
+      const double v = (double)__uint_as_float(absmax_bits[(size_t)n * absmax_parts + i]);
+      m = fmax(m, v * v);
+    }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
   if ((t & 63) == 0) red[t >> 6] = m;
   __syncthreads();
   if (t == 0) {
     double bound = sqrt(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
-    if (absmax_bits) bound = fmax(bound, (double)__uint_as_float(absmax_bits[n]));
     int k = 0;
     if (bound > 0.0 && bound < INFINITY) {
       int e;
@@ -207,9 +211,10 @@ __global__ __launch_bounds__(256) void act_pow2_scale_kernel(const double2* __re
 }
 
 int launch_act_pow2_scale(const double2* mom0, int C0, int lo0, int hi0, double cnt0, const double2* mom1, int C1, double cnt1,
-                          const unsigned* absmax_bits, int Ctab, int N, float* scale, float* shift, float* inv, hipStream_t s) {
+                          const unsigned* absmax_bits, int Ctab, int N, float* scale, float* shift, float* inv, hipStream_t s, int absmax_parts) {
   DRM_REQUIRE((mom0 || absmax_bits) && scale && shift && inv && N > 0 && Ctab > 0, "act_pow2_scale: arguments");
-  hipLaunchKernelGGL(act_pow2_scale_kernel, dim3(N), dim3(256), 0, s, mom0, C0, lo0, hi0, cnt0, mom1, C1, cnt1, absmax_bits, Ctab, scale, shift, inv);
+  hipLaunchKernelGGL(act_pow2_scale_kernel, dim3(N), dim3(256), 0, s, mom0, C0, lo0, hi0, cnt0, mom1, C1, cnt1, absmax_bits, absmax_parts, Ctab, scale,
+                     shift, inv);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }

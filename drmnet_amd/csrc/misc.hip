@@ -14,12 +14,12 @@ __device__ __forceinline__ float silu_m(float v) { return v / (1.0f + __expf(-v)
 // ---------------------------------------------------------------------------------------------
 // One thread per pixel: the NCHW reads are coalesced along the pixel axis in every channel plane (the previous (pixel, quad)
 // mapping read 32-byte fragments: 216 us per launch at B = 32, 3x128x256), the NHWC row of CP floats is written as whole float4s.
-// grid (blocks over one image, N): a block never straddles two images, so the optional per-image absmax is a block reduction and
-// at most ONE atomicMax per block (non-negative floats order like their bit patterns) -- skipped when the word already holds a
-// value at least as large (a stale read only costs a redundant atomic; same-address atomics serialise at the memory side).
+// grid (blocks over one image, N): a block never straddles two images, so the optional per-image absmax is a block reduction; every
+// block writes its own word of absmax_part[n][gridDim.x] and the consumer (act_pow2_scale_kernel) folds them -- the 128 blocks of an
+// image run concurrently, so one atomicMax word per image meant 128 same-address atomics serialised at the memory side.
 template <int Q>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ cond, const int* __restrict__ idx,
-                                                          float4* __restrict__ out, int HW, int Cx, int Cc, unsigned* __restrict__ absmax_bits) {
+                                                          float4* __restrict__ out, int HW, int Cx, int Cc, unsigned* __restrict__ absmax_part) {
   const int n = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = p < HW;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < Q; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
   }
-  if (absmax_bits) {
+  if (absmax_part) {
     __shared__ float wmax[4];
     float m = 0.f;
 #pragma unroll
@@ -48,11 +48,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-      if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(absmax_bits + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(absmax_bits + n, __float_as_uint(m));
-    }
+    if (threadIdx.x == 0) absmax_part[(size_t)n * gridDim.x + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
   }
 }
 
@@ -73,6 +69,8 @@ __global__ __launch_bounds__(256) void pack_input_generic_kernel(const float* __
   }
   out[(size_t)n * HW * Q + j] = make_float4(v[0], v[1], v[2], v[3]);
 }
+
+int pack_input_absmax_parts(int H, int W) { return (H * W + 255) / 256; }
 
 int launch_pack_input(const float* x, const float* cond, const int* idx, float* out, int N, int H, int W, int Cx, int Cc, int CP, hipStream_t s,
                       unsigned* absmax_bits) {
