@@ -758,6 +758,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) {
         const int img = k / (C::BN * 2), rem = k % (C::BN * 2);
         const int n = cur.n0 + img;
+#ifdef DRM_S2_STAMP
+        if (a.stamp_block & 0x40000) {  // timing experiment: plain stores in place of the contended global atomics (wrong statistics)
+          if (n < a.N) *(reinterpret_cast<double*>(a.stat_out + (size_t)n * a.Cout + cur.co0) + rem) = lst[k];
+        } else
+#endif
         if (n < a.N) atomicAdd(reinterpret_cast<double*>(a.stat_out + (size_t)n * a.Cout + cur.co0) + rem, lst[k]);
         lst[k] = 0.0;
       }
@@ -838,7 +843,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
         }
         fclose(f);
       }
-    } else if (static const char* fl = getenv("DRM_S2_FLAGS"); fl) {  // timing experiments without a timeline: 65536 no output stores, 131072 no epilogue
+    } else if (static const char* fl = getenv("DRM_S2_FLAGS"); fl) {  // timing experiments without a timeline: 65536 no output stores, 131072 no epilogue, 262144 statistics fold by plain stores
       ConvArgs at = a;
       at.stamp_block = atoi(fl) & ~0xFFFF;
       hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ks), dim3(C::NTHR), lds_bytes, s, at);

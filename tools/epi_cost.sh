@@ -9,4 +9,5 @@ for rep in 1 2; do
   echo "as shipped:";        python3 tools/layer_probe.py f16x3 2>/dev/null | tail -2
   echo "no output stores:";  DRM_S2_FLAGS=65536 python3 tools/layer_probe.py f16x3 2>/dev/null | tail -2
   echo "no epilogue:";       DRM_S2_FLAGS=131072 python3 tools/layer_probe.py f16x3 2>/dev/null | tail -2
+  echo "statistics fold without atomics (plain stores, wrong sums):"; DRM_S2_FLAGS=262144 python3 tools/layer_probe.py f16x3 2>/dev/null | tail -2
 done
