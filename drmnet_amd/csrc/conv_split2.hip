@@ -909,12 +909,16 @@ int conv_split_ksplit(const ConvArgs& a) {
 // Fixed-order sum of the split-K slabs (already un-scaled by their launch) + everything the conv epilogue would have added: out = sum_k partial[k] + bias
 // (+ emb[n] + residual), and the per-(image, channel) sums / sums of squares of the result for the next GroupNorm.  The slab
 // order is fixed, so the result does not depend on which workgroup finished first (the atomic accumulation it replaces did).
-// grid (pixel blocks, N), block 256: thread = (channel quad, pixel lane); per-thread fp32 partial statistics, one fp64 atomic per
-// (thread, channel, moment) at the end (fp64 adds of a handful of terms: order effects sit at 2^-53).
+// grid (pixel blocks, N), block 256: thread = (channel quad, pixel lane); per-thread fp32 partial statistics, folded per block in LDS,
+// written as one fp64 pair per (block, channel) to stat_part; the LAST block of an image to arrive (ticket counter) adds the blocks'
+// pairs in block order and stores the table.  No atomics on the statistics either: every block of an image used to end in
+// same-address fp64 atomics, which serialise at ~0.6 us each at the memory side (38 us per launch at batch 1, 68 launches per step).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ partial, size_t slab_f4, int ks, const float* __restrict__ bias,
                                                             const float* __restrict__ emb, int emb_stride, const float* __restrict__ res,
-                                                            float4* __restrict__ out, double2* __restrict__ stat, int HW, int Cout, int px_per_block) {
+                                                            float4* __restrict__ out, double2* __restrict__ stat, double2* __restrict__ stat_part,
+                                                            unsigned* __restrict__ ticket, int HW, int Cout, int px_per_block) {
   __shared__ float red[256][8];
+  __shared__ bool s_last;
   const int n = blockIdx.y, q4 = Cout >> 2;
   const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, HW);
   const int ql = threadIdx.x % 64, pl = threadIdx.x / 64;
@@ -959,23 +963,70 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
             a += (double)red[j * 64 + ql][k];
             c2 += (double)red[j * 64 + ql][4 + k];
           }
-          double* d = reinterpret_cast<double*>(stat + (size_t)n * Cout + 4 * q + k);
-          atomicAdd(d, a);
-          atomicAdd(d + 1, c2);
+          if (gridDim.x == 1) {  // the image's only block: its sums ARE the table
+            double2* d = stat + (size_t)n * Cout + 4 * q + k;
+            *d = make_double2(d->x + a, d->y + c2);
+          } else {
+            stat_part[((size_t)n * gridDim.x + blockIdx.x) * Cout + 4 * q + k] = make_double2(a, c2);
+          }
         }
       }
       __syncthreads();
     }
   }
+  if (stat && gridDim.x > 1) {
+    __threadfence();  // this block's pairs are visible device-wide before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket + n, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      for (int c = threadIdx.x; c < Cout; c += 256) {
+        double a = 0.0, c2 = 0.0;
+        const double2* sp = stat_part + (size_t)n * gridDim.x * Cout + c;
+        unsigned b = 0;
+        for (; b + 8 <= gridDim.x; b += 8) {  // eight independent loads in flight, added in block order
+          double2 t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = sp[(size_t)(b + j) * Cout];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            a += t[j].x;
+            c2 += t[j].y;
+          }
+        }
+        for (; b < gridDim.x; ++b) {
+          const double2 t = sp[(size_t)b * Cout];
+          a += t.x;
+          c2 += t.y;
+        }
+        double2* d = stat + (size_t)n * Cout + c;
+        *d = make_double2(d->x + a, d->y + c2);
+      }
+    }
+  }
+}
+
+// pixels per block of the reduction (a multiple of the 4 pixel lanes): about 128 blocks over the whole batch -- the loop is latency-bound,
+// the last block's fold grows with the blocks per image
+static int splitk_reduce_ppb(int N, int HW) {
+  int want = std::max(1, std::min(HW / 4, (128 + N - 1) / N));  // blocks per image
+  if (want <= 4) want = 1;  // a batch that fills the chip by itself: one block per image, nothing to fold
+  return std::max(4, ((HW + want - 1) / want + 3) & ~3);
+}
+int splitk_reduce_blocks(int N, int H, int W) {
+  const int HW = H * W, ppb = splitk_reduce_ppb(N, HW);
+  return (HW + ppb - 1) / ppb;
 }
 
 int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s) {
   DRM_REQUIRE(a.ksplit > 1 && a.split_stride % 4 == 0 && a.Cout % 4 == 0, "split-K reduction arguments");
   const int HW = a.H * a.W;
-  const int ppb = 64;  // pixels per block: 16 per pixel lane (more blocks = more same-address statistics atomics: measured slower at B = 1)
+  const int ppb = splitk_reduce_ppb(a.N, HW);
+  DRM_REQUIRE(!a.stat_out || (a.stat_part && a.stat_ticket), "split-K reduction with statistics needs its partial table and ticket counters");
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((HW + ppb - 1) / ppb, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),
                      a.split_stride / 4, a.ksplit, a.bias, a.emb, a.emb_stride, a.res, reinterpret_cast<float4*>(a.out),
-                     a.stat_out, HW, a.Cout, ppb);
+                     a.stat_out, a.stat_part, a.stat_ticket, HW, a.Cout, ppb);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }

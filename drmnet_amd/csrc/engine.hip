@@ -294,6 +294,11 @@ float* plan_splitk(Ctx& c, ConvArgs& a) {
   a.ksplit = conv_split_ksplit(a);
   if (a.ksplit <= 1) return nullptr;
   a.split_stride = (size_t)a.N * a.H * a.W * a.Cout;
+  // the reduction's per-block statistics pairs and per-image arrival counters (zeroed: from the pass's statistics pool, else here)
+  a.stat_part = c.ar->alloc<double2>((size_t)a.N * splitk_reduce_blocks(a.N, a.H, a.W) * a.Cout);
+  bool zeroed = false;
+  a.stat_ticket = reinterpret_cast<unsigned*>(c.ar->alloc_stats((size_t)a.N * sizeof(unsigned), &zeroed));
+  if (!zeroed && !c.dry()) (void)hipMemsetAsync(a.stat_ticket, 0, (size_t)a.N * sizeof(unsigned), c.s);
   return c.ar->alloc<float>(a.split_stride * a.ksplit);
 }
 
