@@ -207,7 +207,6 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
   f32x16m acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll 4
   for (int kb = 0; kb < I / 16; ++kb) {
     const float4 a0 = pi[4 * kb], a1 = pi[4 * kb + 1];
     const float4 w0 = pw[4 * kb], w1 = pw[4 * kb + 1];
