@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Fixed per-tile cost of the fused 3x3 conv: times one launch (profiler kind 0) of Cin -> Cout at a map size for the epilogue variants
-(plain / + emb / + residual) and a sweep over Cin; the intercept of time(Cin) is what a tile pays besides its K loop."""
+"""Fixed per-tile cost of the fused 3x3 conv through the op-level entry (drm_op_norm_act_conv): one launch (profiler kind 0) of Cin -> Cout
+at a map size for the epilogue variants (plain / + emb / + residual) and a sweep over Cin; the intercept of time(Cin) is what a tile pays
+besides its K loop.  NOTE: the op-level entry stores NCHW without fused statistics -- the networks' own NHWC + statistics epilogue is
+measured by tools/epi_cost.sh on whole ResBlocks instead."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
