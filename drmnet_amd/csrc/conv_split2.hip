@@ -535,7 +535,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         mma_tap(As + (step & 1) * C::A1_F4, Bs + (step % R) * C::G_F4, 0, [](int) {});
         if (y_first) side();
         ++step;
-        if (n2) wait_vmcnt<BASE + C::A_CNT>();
+        // (ring of 2: the group the next step reads was issued in THIS step, after the activation request: nothing may stay in flight)
+        if (n2 && R > 2) wait_vmcnt<BASE + C::A_CNT>();
         else wait_vmcnt<BASE>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -867,6 +868,12 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   constexpr int TPS = (TAPS == 9) ? 3 : 1;
   constexpr int RG = (TAPS == 9) ? 2 : 4;
   constexpr bool big_ok = (TAPS == 1) || (TH >= 8);
+  if constexpr (TAPS == 1 && TH == 16 && TW == 16 && TERMS == 3) {
+    // 1x1 on big maps with Cout a multiple of 256: 256 output channels per tile (64 x 128 per wave, weight ring of 2).  The 1x1 form pays
+    // its activation staging and its barrier once per 24 MFMAs of a wave; here per 48 (the 64x128-map skip convs: 11-15 % faster).  The
+    // 1x1 kernel has the registers for it (176 -> 256 VGPRs, 2 spilled); the 3x3 kernel does not.
+    if (a.Cout % 256 == 0 && wgs(256, 256) >= 512 && a.w_img_stride_f4 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 4, 2, 1, TERMS>(a, s);
+  }
   if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) {
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
