@@ -873,6 +873,9 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     // its activation staging and its barrier once per 24 MFMAs of a wave; here per 48 (the 64x128-map skip convs: 11-15 % faster).  The
     // 1x1 kernel has the registers for it (176 -> 256 VGPRs, 2 spilled); the 3x3 kernel does not.
     if (a.Cout % 256 == 0 && wgs(256, 256) >= 512 && a.w_img_stride_f4 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 4, 2, 1, TERMS>(a, s);
+    // ... and 192 channels per tile (64 x 96 per wave, ring of 3) for Cout = 384 / 1152 / 1536 ...: qkv 512->1536 @16x32 and the 32x64-map skip
+    // convs 12-16 % faster
+    if (a.Cout % 192 == 0 && wgs(256, 192) >= 512 && a.w_img_stride_f4 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
   }
   if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) {
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
