@@ -856,6 +856,8 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
   return DRM_OK;
 }
 
+constexpr long long S2_MIN_WIDE_TILES = 176;  // 256 x 128 tiles are used from this many workgroups on (of 256 CUs)
+
 // 256-pixel x {128, 64}-channel tiles on 8 waves, 128-pixel x {64, 32}-channel tiles on 4 waves
 template <int TAPS, int TH, int TW, int TH4, int TW4, int TERMS>
 static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
@@ -877,7 +879,9 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     // convs 12-16 % faster
     if (a.Cout % 192 == 0 && wgs(256, 192) >= 512 && a.w_img_stride_f4 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
   }
-  if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) {
+  // (one round of 128-wide tiles on >= 176 of the 256 CUs beats two rounds of the less efficient 64-wide ones: qkv 640->1920 @8x16 27 %,
+  //  512->1536 @8x16 24 %, 3x3 384->384 @16x32 12 % faster than with the old "fill every CU" rule)
+  if (a.Cout % 128 == 0 && wgs(256, 128) >= S2_MIN_WIDE_TILES) {
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
   }
@@ -907,7 +911,7 @@ int conv_split_ksplit(const ConvArgs& a) {
   if (a.taps != 9 || a.out_nchw) return 1;
   const long long rows = (long long)a.N * a.H * a.W;
   auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
-  if (a.Cout % 128 == 0 && wgs(256, 128) >= 256) return 1;
+  if (a.Cout % 128 == 0 && wgs(256, 128) >= S2_MIN_WIDE_TILES) return 1;
   if (a.Cout % 64 == 0 && wgs(256, 64) >= 256) return 1;
   if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return 1;
   const long long tiles = wgs(128, 32);
