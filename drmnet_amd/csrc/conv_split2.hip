@@ -874,10 +874,10 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     // 1x1 on big maps with Cout a multiple of 256: 256 output channels per tile (64 x 128 per wave, weight ring of 2).  The 1x1 form pays
     // its activation staging and its barrier once per 24 MFMAs of a wave; here per 48 (the 64x128-map skip convs: 11-15 % faster).  The
     // 1x1 kernel has the registers for it (176 -> 256 VGPRs, 2 spilled); the 3x3 kernel does not.
-    if (a.Cout % 256 == 0 && wgs(256, 256) >= 512 && a.w_img_stride_f4 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 4, 2, 1, TERMS>(a, s);
+    if (a.Cout % 256 == 0 && wgs(256, 256) >= 512) return launch_s2<TAPS, TH, TW, 4, 2, 2, 4, 2, 1, TERMS>(a, s);
     // ... and 192 channels per tile (64 x 96 per wave, ring of 3) for Cout = 384 / 1152 / 1536 ...: qkv 512->1536 @16x32 and the 32x64-map skip
     // convs 12-16 % faster
-    if (a.Cout % 192 == 0 && wgs(256, 192) >= 512 && a.w_img_stride_f4 == 0) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
+    if (a.Cout % 192 == 0 && wgs(256, 192) >= 512) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
   }
   // (one round of 128-wide tiles on >= 176 of the 256 CUs beats two rounds of the less efficient 64-wide ones: qkv 640->1920 @8x16 27 %,
   //  512->1536 @8x16 24 %, 3x3 384->384 @16x32 12 % faster than with the old "fill every CU" rule)
