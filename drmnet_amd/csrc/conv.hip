@@ -16,6 +16,8 @@
 // double-buffered [kgroup][cout][4] LDS tile, one tap at a time, prefetched into registers under the MFMAs.
 // Math: v_mfma_f32_32x32x2_f32 (exact fp32, 256 FLOP/clk/CU); each wave holds MT x NT 32x32 accumulators.
 // K order inside a chunk is permuted (lane half h takes k-groups 2j+h) so one b128 read feeds 4 MFMAs.
+#include <atomic>
+
 #include "common.h"
 #include "profiler.h"
 
@@ -257,10 +259,13 @@ static int launch_variant(const ConvArgs& a, hipStream_t s) {
   using C = Cfg<TAPS, TH, TW, WM, WN, MT, NT, KC>;
   auto kern = conv_igemm_kernel<TAPS, TH, TW, WM, WN, MT, NT, KC>;
   const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
-  static bool attr_set = false;
-  if (!attr_set && lds_bytes > 48 * 1024) {
+  // the opt-in LDS size is a per-device function attribute: one bit per device ordinal, set idempotently (as in conv_split2.hip)
+  const DeviceInfo* di = device_info();
+  if (!di) return DRM_ERR_STATE;
+  static std::atomic<uint64_t> attr_mask{0};
+  if (lds_bytes > 48 * 1024 && !(attr_mask.load(std::memory_order_acquire) >> di->ordinal & 1)) {
     DRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
+    attr_mask.fetch_or(uint64_t(1) << di->ordinal, std::memory_order_release);
   }
   const int groups = (a.N + C::TN - 1) / C::TN;
   const long long blocks = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
