@@ -152,8 +152,17 @@ class _HipUNetBase(nn.Module):
 
     # ------------------------------------------------------------------ weights
     def param_tensors(self) -> List[torch.Tensor]:
-        sd = dict(self.named_parameters())
-        return [sd[k] for k in self._keys]
+        # the Parameter objects are stable (load_state_dict copies in place, .to() / .cuda() swap their .data): looked up once
+        ps = self.__dict__.get("_param_list")
+        if ps is None or len(ps) != len(self._keys):
+            sd = dict(self.named_parameters())
+            ps = [sd[k] for k in self._keys]
+            self.__dict__["_param_list"] = ps
+        return ps
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .float(): drop the memoised parameter list with the old storage
+        self.__dict__.pop("_param_list", None)
+        return super()._apply(fn, *args, **kwargs)
 
     SETS = {"live": 0, "ema": 1}
 
