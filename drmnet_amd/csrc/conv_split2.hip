@@ -143,6 +143,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 // before every ds_read of the loop (it does when the __builtin_amdgcn_global_load_lds form is used next to LDS reads of
 // the same array); completion is tracked by the counted waits below.  M0 carries the LDS base and is restored
 // (cdna_hip_programming.md 5.7).
+// Same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the per-instruction address arithmetic is scalar, no
+// VALU instruction goes into the MFMA stream for it.
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -345,6 +354,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   //      `gseq` counts groups since kernel start (ring slot = gseq % R); (g_in_tile, co0) say which weights.
   const unsigned lds_bs = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Bs));  // LDS byte offset of the ring
+  // per-lane byte offset of the j-th 1-KiB piece inside a weight tile (the tile's base is wave-uniform: scalar registers)
+  unsigned dma_voff[C::B_PER];
+#pragma unroll
+  for (int j = 0; j < C::B_PER; ++j) {
+    const int idx = (wave * 64 + C::NTHR * j) % C::B_DMA_F4 + lane;
+    dma_voff[j] = (unsigned)((idx / C::BN) * a.Cout + idx % C::BN) * 16u;
+  }
   // k-th LDS-DMA instruction (0 .. G_PER-1) of a group
   auto issue_G1 = [&](int gseq, int g_in_tile, long long co0, int k) {
     const int slot = gseq % R;
@@ -356,9 +372,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     // upper waves re-fetch a piece (same bytes to the same LDS address) so that EVERY wave issues the same number of
     // vector-memory operations -- the counted waits rely on that.
     const int base = (wave * 64 + C::NTHR * j) % C::B_DMA_F4;
-    const int idx = base + lane;
-    const int seg = idx / C::BN, co = idx % C::BN;
-    glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
+    unsigned vo = dma_voff[0];
+#pragma unroll
+    for (int jj = 1; jj < C::B_PER; ++jj) vo = (j == jj) ? dma_voff[jj] : vo;
+    glds16s(wp, vo, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
   };
   auto issue_G = [&](int gseq, int g_in_tile, long long co0) {
     const int slot = gseq % R;
@@ -370,9 +387,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #pragma unroll
       for (int j = 0; j < C::B_PER; ++j) {
         const int base = (wave * 64 + C::NTHR * j) % C::B_DMA_F4;  // (see issue_G1)
-        const int idx = base + lane;
-        const int seg = idx / C::BN, co = idx % C::BN;
-        glds16(wp + (size_t)seg * a.Cout + co, lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
+        glds16s(wp, dma_voff[j], lds_bs + (unsigned)(slot * C::G_F4 + u * C::B_F4 + base) * 16u);
       }
     }
   };
