@@ -167,10 +167,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gload16x2(f32x4& d0, f32x4& d1, const void* p) {
   asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(d0), "=&v"(d1) : "v"(p) : "memory");
 }
-// ... and with a wave-uniform base in SGPRs + a 32-bit per-lane byte offset (see glds16s)
-__device__ __forceinline__ void gload16x2s(f32x4& d0, f32x4& d1, const void* sbase, unsigned voff) {
-  asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16" : "=&v"(d0), "=&v"(d1) : "v"(voff), "s"(sbase) : "memory");
-}
 __device__ __forceinline__ void tie_regs(f32x4& x0, f32x4& x1) { asm volatile("" : "+v"(x0), "+v"(x1)::"memory"); }
 
 // 4 x 4 transpose across the four lanes of a quad: in, lane q holds x_k = M[q][k]; out, lane q holds x_k = M[k][q].
@@ -296,11 +292,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       const bool ok = (lidx < C::HPI * C::OCT) && (l_n < a.N) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
       const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
       const int ys = up ? (yc >> 1) : yc, xs = up ? (xc >> 1) : xc;
-      // uniform part (source, channel chunk, and the image when a tile holds one) in scalar registers; the per-lane part is a 32-bit byte
-      // offset (multi-image tiles only exist on maps of <= 128 pixels: launch_s2 checks that their tensors stay below 4 GiB)
-      const float* sb = src + coff + (C::TN == 1 ? (size_t)tp.n0 * Hs * Ws * Cs : (size_t)0);
-      const unsigned vo = (unsigned)((((C::TN == 1 ? 0 : l_nc * Hs) + ys) * Ws + xs) * Cs + 8 * l_o) * 4u;
-      gload16x2s(areg[j][0], areg[j][1], sb, vo);
+      const size_t pix = ((size_t)l_nc * Hs + ys) * Ws + xs;
+      gload16x2(areg[j][0], areg[j][1], src + pix * Cs + coff + 8 * l_o);
       if (ok) avalid |= 1u << j;
     }
     if (piece == C::A_SLOTS) {  // always 4 loads (a harmless re-read of the input when there is no GroupNorm) so every chunk issues A_CNT loads
@@ -825,9 +818,6 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
   const int groups = (a.N + C::TN - 1) / C::TN;
   const long long tiles = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
   DRM_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv grid size");
-  DRM_REQUIRE((double)a.N * a.H * a.W * std::max(a.ld0 ? a.ld0 : a.C0, a.C1) * 4.0 < 4294967296.0 || C::TN == 1,
-              "multi-image tiles address a source tensor with 32-bit byte offsets");
-  DRM_REQUIRE((double)a.H * a.W * std::max(a.ld0 ? a.ld0 : a.C0, a.C1) * 4.0 < 4294967296.0 && (double)a.N * (a.C0 + a.C1) * 4.0 < 4294967296.0, "conv: image too large");
   // persistent grid: as many workgroups as stay resident (256 CUs x workgroups per CU by LDS), a multiple of 8 (XCDs)
   const int per_cu = std::max(1, std::min((int)(di->lds_per_cu / lds_bytes), 8 / C::NW));
   long long grid = (long long)di->cus * per_cu;
