@@ -896,6 +896,12 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   }
   // (one round of 128-wide tiles on >= 176 of the 256 CUs beats two rounds of the less efficient 64-wide ones: qkv 640->1920 @8x16 27 %,
   //  512->1536 @8x16 24 %, 3x3 384->384 @16x32 12 % faster than with the old "fill every CU" rule)
+  if constexpr (TAPS == 9 && TH == 16 && TW == 16 && TERMS == 3) {
+    // 3x3 with 192 output channels per tile (64 x 96 per wave; one-tap weight ring of 3: the three-tap groups would not fit next to the
+    // halo tile) for Cout = 384 on big maps: 12 fragment reads per 18 MFMA products instead of 8 per 12 -- 5 % faster there.  Fits since
+    // the scalar-base DMA addressing took the kernel from 256 to 207 VGPRs.
+    if (a.Cout % 192 == 0 && wgs(256, 192) >= 512) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
+  }
   if (a.Cout % 128 == 0 && wgs(256, 128) >= S2_MIN_WIDE_TILES) {
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
