@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-strict-fp32", action="store_true", help="skip the short exact-fp32 pass that follows the headline measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (B = 128 / B = 1 steps, ObsNet DDIM chain at B = 256, full chain) that follow it")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the batch-1 parity forward passes (keeps a rocprofv3 trace of this command to the timed workload's launches)")
     return ap.parse_args()
 
@@ -89,6 +90,26 @@ def build_models(workload, dev, precision="fp32"):
     return m.to(dev)
 
 
+def chain_inputs(B, dev, radius=128):
+    """B synthetic objects for the full chain: a shaded, textured unit sphere seen by an orthographic camera
+    (normals as utils/transform.py:147-167), 256x256 HDR image + normals + mask each."""
+    import numpy as np
+    from drmnet_amd import synth
+
+    lin = np.linspace(-radius + 0.5, radius - 0.5, 2 * radius)
+    xx, yy = np.meshgrid(lin, lin[::-1])
+    zsq = radius ** 2 - (xx ** 2 + yy ** 2)
+    nrm = np.stack([xx, yy, np.sqrt(np.clip(zsq, 0, None))], -1).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    nrm[zsq < 0] = 0
+    normals = torch.from_numpy(nrm).to(dev).expand(B, -1, -1, -1).contiguous()
+    masks = torch.linalg.norm(normals, dim=-1) > 0.5
+    g = torch.Generator().manual_seed(synth.SEED_INPUT)
+    imgs = (torch.exp(torch.randn((B, 2 * radius, 2 * radius, 3), generator=g) * 0.5 - 2.0)).to(dev)
+    imgs = imgs * (0.2 + normals[..., 2:3].clamp_min(0))
+    return imgs, normals, masks
+
+
 def make_step(args, model, dev):
     """Returns (callable running ONE step on the current stream, algorithmic GFLOP per sample-step, description)."""
     from drmnet_amd import _lib, synth
@@ -97,23 +118,11 @@ def make_step(args, model, dev):
     if args.workload == "estimate_chain":
         # BASELINE configs[4] / SURVEY 8d config 5: object image + normals + mask -> refmap -> ObsNet DDIM-50 -> DRMNet loop
         # (150 steps, early exit off so the work is countable) -> Lr0, at the config shape (128x128 refmaps from 256x256 images)
-        import numpy as np
         from drmnet_amd.estimate import estimate_batch
 
         drm, obs = model
         res = drm.ds.size
-        radius = 128
-        lin = np.linspace(-radius + 0.5, radius - 0.5, 2 * radius)
-        xx, yy = np.meshgrid(lin, lin[::-1])
-        zsq = radius ** 2 - (xx ** 2 + yy ** 2)
-        nrm = np.stack([xx, yy, np.sqrt(np.clip(zsq, 0, None))], -1).astype(np.float32)
-        nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
-        nrm[zsq < 0] = 0  # unit-sphere normals seen by an orthographic camera (utils/transform.py:147-167)
-        normals = torch.from_numpy(nrm).to(dev).expand(B, -1, -1, -1).contiguous()
-        masks = torch.linalg.norm(normals, dim=-1) > 0.5
-        g = torch.Generator().manual_seed(synth.SEED_INPUT)
-        imgs = (torch.exp(torch.randn((B, 2 * radius, 2 * radius, 3), generator=g) * 0.5 - 2.0)).to(dev)
-        imgs = imgs * (0.2 + normals[..., 2:3].clamp_min(0))  # a shaded sphere with per-pixel texture
+        imgs, normals, masks = chain_inputs(B, dev)
         state = {"n": 0}
 
         def step():
@@ -332,12 +341,14 @@ def strict_fp32_pass(args, model, dev, L, _lib):
     torch.cuda.synchronize(dev)
     L.drm_profile_reset()
     L.drm_profile_enable(2)
-    n = 4
-    t0 = time.perf_counter()
+    n = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(n):
         step()
+    e1.record()
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    dt = e0.elapsed_time(e1) * 1e-3  # device time between two events on the launch stream
     L.drm_profile_enable(0)
     K0 = 5
     tm, tf, tb, tn = (C.c_double * K0)(), (C.c_double * K0)(), (C.c_double * K0)(), (C.c_int64 * K0)()
@@ -347,6 +358,90 @@ def strict_fp32_pass(args, model, dev, L, _lib):
             "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)",
             "roofline": None if ach is None else {"bound": "mfma", "kernel": "conv_igemm_kernel<9,...>", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(tm[0] / max(tn[0], 1), 4)}}
+
+
+def secondary_pass(args, model, dev):
+    """The rest of BASELINE's metric and configs in the same driver line, each a short device-timed run AFTER the
+    headline measurement: the DRMNet step at 128 refmaps per GPU (north-star: batch 1024 over 8 GPUs) and at batch 1 @128x128 (the
+    reference's own use, scripts/estimate.py), the ObsNet DDIM-50 chain at batch 256 (configs[2]; fp32-accurate split mode and the
+    reduced-precision f16 mode, eager and hipGraph replay), and the full chain object image -> Lr0 (configs[4], metric part 2:
+    "full-chain samples/sec") at 32 objects per GPU with per-stage device time."""
+    import copy
+
+    from drmnet_amd import ops
+    from drmnet_amd.config import instantiate_from_config, load_config
+    from drmnet_amd.ddim import DDIMSampler
+    from drmnet_amd.estimate import estimate_batch
+    from drmnet_amd import synth
+
+    def timed(fn, n, warm=1):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e-3 / n
+
+    out = {"note": "device time between two events on the launch stream; same seeded synthetic weights and inputs as the headline"}
+    unit = "denoise steps/sec (samples x steps / s)"
+    for name, (b, h, w, n) in {"drmnet_step_b128_3x128x256": (128, 128, 256, 4), "drmnet_step_b1_3x128x128": (1, 128, 128, 30)}.items():
+        a = copy.copy(args)
+        a.batch, a.height, a.width = b, h, w
+        step, _, _ = make_step(a, model, dev)
+        dt = timed(step, n, warm=2)
+        out[name] = {"value": round(b / dt, 2), "unit": unit, "ms_per_step": round(dt * 1e3, 3), "steps": n, "precision": args.precision}
+    torch.cuda.empty_cache()
+
+    # ---- ObsNet DDIM-50 chain, batch 256 @3x128x256 (BASELINE configs[2])
+    obs = build_models("obsnet", dev, "f16x3")
+    x = synth.synth_refmaps(256, 128, 256, synth.SEED_INPUT).to(dev)
+    xT = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+    chains = {}
+    for prec in ("f16x3", "f16"):
+        obs.set_precision(prec)
+        smp = DDIMSampler(obs)
+        smp.make_schedule(50, ddim_eta=1.0, verbose=False)
+        for graph in (False, True):
+            ops.set_graph_replay(graph)
+            res = {}
+
+            def chain():
+                res["x"], _ = smp.ddim_sampling(x, tuple(x.shape), x_T=xT, seed=1)
+
+            dt = timed(chain, 1, warm=0 if chains else 1)
+            chains[f"{prec}_{'graph' if graph else 'eager'}"] = {"value": round(256 * 50 / dt, 1), "unit": unit, "s_per_chain": round(dt, 3),
+                                                                  "finite": bool(torch.isfinite(res["x"]).all().item())}
+    ops.set_graph_replay(False)
+    chains["note"] = ("f16x3 = fp32-accurate split mode (1e-4 contract); f16 = fp16 operands, fp32 accumulate: the reduced-precision mode standing in for "
+                      "configs[2]'s bf16 (more mantissa, guarded range; 5e-3 tolerance, tests/test_gpu_configs.py)")
+    out["obsnet_ddim50_chain_b256_3x128x256"] = chains
+    del x, xT
+    torch.cuda.empty_cache()
+
+    # ---- full chain (BASELINE configs[4]; metric part 2): 32 object images per GPU, 256x256 -> 128x128 refmaps
+    obs.set_precision("f16x3")
+    obs.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["data"]["params"]["predict"])
+    model.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/drmnet/eval_drmnet.yaml"))["data"]["params"]["predict"])
+    B = 32
+    imgs, normals, masks = chain_inputs(B, dev)
+    fc = {"objects_per_gpu": B, "refmap": "3x128x128 from 256x256 object images", "ddim_steps": obs.ddim_steps, "max_timesteps": model.max_timesteps}
+    for tag, ee in (("early_exit_off", False), ("natural_early_exit", True)):
+        estimate_batch(model, obs, imgs, normals, masks, early_exit=ee, seed=7)  # warm-up (workspace, kernel attributes)
+        tm = {}
+        t0 = time.perf_counter()
+        _, _, K = estimate_batch(model, obs, imgs, normals, masks, early_exit=ee, seed=8, hooks={"timing": tm})
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        steps = int(K.sum().item()) if ee else B * model.max_timesteps
+        fc[tag] = {"value": round(B / dt, 3), "unit": "object images/sec", "s_per_batch": round(dt, 3), "stage_ms": {k: round(v, 1) for k, v in tm.items()},
+                   "drmnet_sample_steps": steps, "K_min_max": [int(K.min().item()), int(K.max().item())]}
+    fc["note"] = ("value = whole-call wall time (host included). Random-weight networks do not converge the way trained ones do: the natural-exit row shows the "
+                  "early-exit machinery at whatever K the synthetic RefNet produces; the early-exit-off row is the countable one (150 steps per object)")
+    out["full_chain"] = fc
+    return out
 
 
 def main():
@@ -496,6 +591,9 @@ def main():
             out["parity_check"] = parity_check(model, dev, args.precision)
         if world == 1 and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_strict_fp32:
             out["strict_fp32"] = strict_fp32_pass(args, model, dev, L, _lib)
+        if world == 1 and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_secondary and (args.batch, args.height, args.width) == (32, 128, 256):
+            model.set_precision("f16x3")
+            out["secondary"] = secondary_pass(args, model, dev)
         if world == 1 and not args.no_cpu_baseline and args.workload == "drmnet_step":
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -949,8 +949,8 @@ int conv_split_ksplit(const ConvArgs& a) {
 // pairs in block order and stores the table.  No atomics on the statistics either: every block of an image used to end in
 // same-address fp64 atomics, which serialise at ~0.6 us each at the memory side (38 us per launch at batch 1, 68 launches per step).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ partial, size_t slab_f4, int ks, const float* __restrict__ bias,
-                                                            const float* __restrict__ emb, int emb_stride, const float* __restrict__ res,
-                                                            float4* __restrict__ out, double2* __restrict__ stat, double2* __restrict__ stat_part,
+                                                            const float* __restrict__ emb, int emb_stride, const float* res /* may alias out: skip_connection blocks */,
+                                                            float4* out, double2* __restrict__ stat, double2* __restrict__ stat_part,
                                                             unsigned* __restrict__ ticket, int HW, int Cout, int px_per_block) {
   __shared__ float red[256][8];
   __shared__ bool s_last;

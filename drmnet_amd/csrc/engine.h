@@ -118,7 +118,7 @@ class UNet {
 
   int build(const drm_unet_desc& d);
   int load(const float* const* ptrs, int count, hipStream_t s, int set);
-  std::map<std::tuple<int, int, int>, size_t> stats_pool_cache;  // (N, H, W) -> bytes of the statistics pool
+  std::map<std::tuple<int, int, int, int>, size_t> stats_pool_cache;  // (N, H, W, precision) -> bytes of the statistics pool (split-K tickets live in it)
   int forward(const float* x, int Cx, const float* cond, int Cc, const int32_t* rows, const float* t_emb, const int64_t* t, const float* tf,
               float* out, int N, int H, int W, Arena& ar, hipStream_t s);
   ~UNet();

@@ -376,7 +376,15 @@ int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, f
                             cnt(x0), x1 ? cnt(*x1) : 0.0, gs, gh, gi);
 }
 
+// a real pass whose arena ran out hands out null tables: stop before any kernel is launched on them
+static int arena_ok(const Ctx& c) {
+  if (!c.ar->failed) return DRM_OK;
+  set_error("workspace too small: need more than " + std::to_string(c.ar->cap) + " bytes (query drm_unet_workspace_bytes for this shape and precision)");
+  return DRM_ERR_WORKSPACE;
+}
+
 int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out) {
+  DRM_TRY(arena_ok(c));
   const int H = x0.H, W = x0.W;
   const int C0 = x0.C, C1 = x1 ? x1->C : 0;
   DRM_REQUIRE(C0 + C1 == r.cin, "resblock input channels");
@@ -426,6 +434,7 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
 
 int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out) {
   DRM_REQUIRE(!x.up && x.C == l.ch, "attention input");
+  DRM_TRY(arena_ok(c));
   const int H = x.H, W = x.W, T = H * W, C = l.ch;
   const size_t mark = c.ar->mark();
   float* sc = c.ar->alloc<float>((size_t)c.N * C);
@@ -484,7 +493,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   ar.st_active = true;
   ar.st_off = 0;
   if (!ar.dry) {
-    const auto key = std::make_tuple(N, H, W);
+    const auto key = std::make_tuple(N, H, W, precision);  // the split modes carve their split-K ticket counters out of the pool
     auto it = stats_pool_cache.find(key);
     if (it == stats_pool_cache.end()) {
       Arena probe;
@@ -512,6 +521,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   float* e1 = c.ar->alloc<float>((size_t)N * emb_dim);
   float* emb = c.ar->alloc<float>((size_t)N * emb_dim);
   float* emb_all = c.ar->alloc<float>((size_t)N * emb_total);
+  DRM_TRY(arena_ok(c));
   if (!c.dry()) {
     DRM_TRY(launch_pack_input(x, cond, rows, xin.p, N, H, W, Cx, Cc, in_cp, s, amax));
     const float* te = t_emb;
@@ -554,6 +564,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
       } else if (l.kind == Layer::DOWN) {
         DRM_REQUIRE(!h->up, "downsample of an upsampled tensor");
         Act* o = make(h->C, h->H / 2, h->W / 2);
+        DRM_TRY(arena_ok(c));
         if (!c.dry()) {
           if (!o->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(o->mom, 0, (size_t)N * o->C * sizeof(double2), s));
           DRM_TRY(launch_avgpool2(h->p, o->p, N, h->H, h->W, h->C, s, o->mom));  // pooled tensor + its GroupNorm sums in one pass
@@ -586,6 +597,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   DRM_REQUIRE(!h->up && h->C == final_ch, "head input");
   float* sc = c.ar->alloc<float>((size_t)N * final_ch);
   float* sh = c.ar->alloc<float>((size_t)N * final_ch);
+  DRM_TRY(arena_ok(c));
   DRM_TRY(gn_params(c, *h, nullptr, Wb + on_w, Wb + on_b, sc, sh));
   if (!c.dry()) {
     if (desc.kind == 0) {

@@ -12,7 +12,9 @@
 #include "samplers.h"
 #include "profiler.h"
 
+#include <atomic>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace drm {
@@ -146,6 +148,7 @@ __global__ void drmnet_record_kernel(const int32_t* __restrict__ rows, const int
 // counter, so the launches of a step do not depend on j and one captured hipGraph of a step can be replayed for the whole chain
 // (BASELINE configs[2]: "hipGraph-captured step").  Table row layout: STEP_ROW floats.
 constexpr int STEP_ROW = 8;  // [0] timestep, [1..5] coefficients, [6] flag (DDPM: t > 0), [7] unused
+constexpr int MAX_TABLE_STEPS = 4096;  // sampler_workspace_bytes budgets the table for this many steps; the chain entry points check it
 
 __global__ void step_begin_kernel(const float* __restrict__ tab, const int* __restrict__ counter, float* __restrict__ tf, int N) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,18 +343,38 @@ size_t sampler_workspace_bytes(UNet* net, int N, int H, int W) {
   if (net->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a, nullptr) != DRM_OK) return 0;
   const size_t chw = (size_t)net->desc.out_channels * H * W;
   // U-Net arena + eps [N,C,H,W] + timesteps [N] + the per-step scalar table (<= 4096 steps) and its counter
-  return a.peak + ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + (4096 * 8 * sizeof(float) + 256) + 1024;
+  return a.peak + ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + ((size_t)MAX_TABLE_STEPS * STEP_ROW * sizeof(float) + 256) + 1024;
 }
 
 // Runs `steps` identical-launch steps: the first eagerly (it also sizes caches and sets per-kernel attributes), the second under
 // stream capture, the rest as replays of that graph.  Falls back to eager launches when replay is switched off, the launch
 // profiler is recording (its events do not belong in a graph) or the chain is too short to pay for an instantiation.
-static bool g_graph_replay = false;  // measured: no faster at B = 32 / 256 (kernels already cover ~95 % of the wall time), slower at B = 1
-static long long g_graph_launches = 0;
-void set_graph_replay(bool on) { g_graph_replay = on; }
-long long graph_launches() { return g_graph_launches; }
+static std::atomic<bool> g_graph_replay{false};  // measured: no faster at B = 32 / 256 (kernels already cover ~95 % of the wall time), slower at B = 1
+static std::atomic<long long> g_graph_launches{0};
+void set_graph_replay(bool on) { g_graph_replay.store(on); }
+long long graph_launches() { return g_graph_launches.load(); }
 
-static bool graph_wanted(int steps) { return g_graph_replay && !prof_enabled() && steps >= 4; }
+static bool graph_wanted(int steps) { return g_graph_replay.load() && !prof_enabled() && steps >= 4; }
+
+// Per-(thread, device) helper objects: a private capture stream + ordering event, and a pinned staging buffer for the step tables.
+struct ThreadDev {
+  hipStream_t priv = nullptr;
+  hipEvent_t ev = nullptr;
+  void* pinned = nullptr;       // step-table staging (host, page-locked)
+  size_t pinned_cap = 0;
+  hipEvent_t pinned_ev = nullptr;  // recorded behind the last copy out of `pinned`
+  bool pinned_busy = false;
+};
+static ThreadDev* thread_dev() {
+  constexpr int MAX_DEV = 64;
+  static thread_local ThreadDev td[MAX_DEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+    set_error("sampler: no current HIP device");
+    return nullptr;
+  }
+  return &td[dev];
+}
 
 // The legacy default stream (what PyTorch hands over unless the caller set a stream) cannot be captured: a chain that will be
 // replayed runs on a private non-blocking stream ordered behind the caller's stream by an event; run_steps drains it before it
@@ -359,15 +382,15 @@ static bool graph_wanted(int steps) { return g_graph_replay && !prof_enabled() &
 static int chain_stream(hipStream_t caller, int steps, hipStream_t* out) {
   *out = caller;
   if (caller != nullptr || !graph_wanted(steps)) return DRM_OK;
-  static thread_local hipStream_t priv = nullptr;
-  static thread_local hipEvent_t ev = nullptr;
-  if (!priv) {
-    DRM_HIP_CHECK(hipStreamCreateWithFlags(&priv, hipStreamNonBlocking));
-    DRM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  ThreadDev* t = thread_dev();
+  if (!t) return DRM_ERR_STATE;
+  if (!t->priv) {
+    DRM_HIP_CHECK(hipStreamCreateWithFlags(&t->priv, hipStreamNonBlocking));
+    DRM_HIP_CHECK(hipEventCreateWithFlags(&t->ev, hipEventDisableTiming));
   }
-  DRM_HIP_CHECK(hipEventRecord(ev, caller));
-  DRM_HIP_CHECK(hipStreamWaitEvent(priv, ev, 0));
-  *out = priv;
+  DRM_HIP_CHECK(hipEventRecord(t->ev, caller));
+  DRM_HIP_CHECK(hipStreamWaitEvent(t->priv, t->ev, 0));
+  *out = t->priv;
   return DRM_OK;
 }
 
@@ -400,7 +423,7 @@ static int run_steps(int steps, hipStream_t s, Body&& body) {
       set_error("hipGraphLaunch failed while replaying a sampler step");
       status = DRM_ERR_HIP;
     }
-    ++g_graph_launches;
+    g_graph_launches.fetch_add(1);
   }
   // the executable graph must outlive its last launch: the stream is drained before it is destroyed
   if (hipStreamSynchronize(s) != hipSuccess && status == DRM_OK) {
@@ -412,10 +435,28 @@ static int run_steps(int steps, hipStream_t s, Body&& body) {
   return status;
 }
 
-// uploads the per-step table (host rows -> device) and zeroes the step counter
+// uploads the per-step table (host rows -> device) and zeroes the step counter.  The rows go through a page-locked staging buffer
+// owned by (thread, device); the only wait is for the PREVIOUS chain's copy out of that buffer, long retired in steady state.
 static int upload_step_table(const std::vector<float>& rows, float* tab, int* counter, hipStream_t s) {
-  DRM_HIP_CHECK(hipMemcpyAsync(tab, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, s));
-  DRM_HIP_CHECK(hipStreamSynchronize(s));  // `rows` is pageable host memory owned by the caller's frame
+  ThreadDev* t = thread_dev();
+  if (!t) return DRM_ERR_STATE;
+  const size_t bytes = rows.size() * sizeof(float);
+  if (t->pinned_busy) {
+    DRM_HIP_CHECK(hipEventSynchronize(t->pinned_ev));
+    t->pinned_busy = false;
+  }
+  if (bytes > t->pinned_cap) {
+    if (t->pinned) (void)hipHostFree(t->pinned);
+    t->pinned = nullptr;
+    t->pinned_cap = 0;
+    DRM_HIP_CHECK(hipHostMalloc(&t->pinned, bytes, hipHostMallocDefault));
+    t->pinned_cap = bytes;
+  }
+  if (!t->pinned_ev) DRM_HIP_CHECK(hipEventCreateWithFlags(&t->pinned_ev, hipEventDisableTiming));
+  memcpy(t->pinned, rows.data(), bytes);
+  DRM_HIP_CHECK(hipMemcpyAsync(tab, t->pinned, bytes, hipMemcpyHostToDevice, s));
+  DRM_HIP_CHECK(hipEventRecord(t->pinned_ev, s));
+  t->pinned_busy = true;
   DRM_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
   return DRM_OK;
 }
@@ -424,6 +465,7 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
                 uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddim needs a UNetModel");
   DRM_REQUIRE(S >= 1 && timesteps && coef, "ddim schedule");
+  DRM_REQUIRE(S <= MAX_TABLE_STEPS, "ddim: at most " + std::to_string(MAX_TABLE_STEPS) + " steps (the workspace budgets the step table for that many)");
   const int Cx = net->desc.out_channels, Cc = net->desc.in_channels - Cx;
   const size_t n = (size_t)N * Cx * H * W;
   const int steps = (num_steps > 0 && num_steps < S) ? num_steps : S;
@@ -459,6 +501,7 @@ int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const fl
                 uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddpm needs a UNetModel");
   DRM_REQUIRE(T_start >= 1 && coef, "ddpm schedule");
+  DRM_REQUIRE(T_start <= MAX_TABLE_STEPS, "ddpm: at most " + std::to_string(MAX_TABLE_STEPS) + " steps (the workspace budgets the step table for that many)");
   hipStream_t s;
   DRM_TRY(chain_stream(caller, T_start, &s));
   const int Cx = net->desc.out_channels, Cc = net->desc.in_channels - Cx;

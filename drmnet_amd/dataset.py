@@ -34,11 +34,16 @@ class BaseDataset(torch.utils.data.Dataset):
         self.clamp_before_exp = 10 if clamp_before_exp is False else clamp_before_exp
         self.Logarithmic_params = None  # [log10min, log10max], each [B, 1, 1, 1] (or [1, 1, 1] for a 3-D input), set by transform(dynamic_normalize=True)
         names = transform_func.split("_")
-        self._forward: List[Tuple[str, float]] = []
-        self._resize_modes: List[str] = []
+        # forward program: elementwise segments (one drm_map_chain pass each) cut at every resize, which keeps its position in the
+        # chain as in the reference (:29-35: log(resize(x)) is not resize(log(x)), and normalizedLogarithmic's statistics are taken at
+        # the resolution its input has at that point)
+        self._forward: List = [[]]
         for name in reversed(names):
-            step = self._compile(name, inverse=False)
-            self._forward.extend(step)
+            if name.startswith("resize"):
+                self._forward.append("bilinear" if name == "resize" else name[len("resize"):].replace("-", "_").lower())
+                self._forward.append([])
+            else:
+                self._forward[-1].extend(self._compile(name, inverse=False))
         self._inverse: List[Tuple[str, float]] = []
         for name in names:
             self._inverse.extend(self._compile(name, inverse=True))
@@ -49,8 +54,6 @@ class BaseDataset(torch.utils.data.Dataset):
             raise NotImplementedError(name)
         cap = float(self.clamp_before_exp) if self.clamp_before_exp else math.inf
         if name.startswith("resize"):
-            if not inverse:
-                self._resize_modes.append("bilinear" if name == "resize" else name[len("resize"):].replace("-", "_").lower())
             return []  # shape change, not an elementwise map: handled in transform(); rescale leaves the size alone (:86-87)
         if name.startswith("lowerbound"):
             return [] if inverse else [("lowerbound", float(name[len("lowerbound"):]))]
@@ -95,15 +98,20 @@ class BaseDataset(torch.utils.data.Dataset):
 
     def transform(self, x: torch.Tensor, dynamic_normalize: bool = False, mask: torch.Tensor = None):
         assert x.size(-1) >= self.size
-        y = self._run(x, self._forward, dynamic_normalize=dynamic_normalize, mask=mask)
-        for mode in self._resize_modes:
-            if y.shape[-1] != self.size or y.shape[-2] != self.size:
+        y = x
+        for seg in self._forward:
+            if isinstance(seg, list):
+                if seg:
+                    y = self._run(y, seg, dynamic_normalize=dynamic_normalize, mask=mask)
+            elif y.shape[-1] != self.size or y.shape[-2] != self.size:
                 # the shipped path never gets here (refmaps are produced at `size`); an actual resize is torch glue, not a kernel
-                aa = mode in ("bilinear", "bicubic")
-                flat = y.reshape(-1, 1, *y.shape[-2:])
-                flat = torch.nn.functional.interpolate(flat, size=(self.size, self.size), mode=mode, antialias=aa, align_corners=False if aa else None)
+                aa = seg in ("bilinear", "bicubic")
+                flat = y.float().reshape(-1, 1, *y.shape[-2:])
+                flat = torch.nn.functional.interpolate(flat, size=(self.size, self.size), mode=seg, antialias=aa, align_corners=False if aa else None)
                 y = flat.reshape(*y.shape[:-2], self.size, self.size)
-        return y
+        if not y.is_cuda:
+            raise RuntimeError("BaseDataset maps run on the GPU (drmnet_amd has no CPU path); got a CPU tensor")
+        return y.float().contiguous()
 
     def rescale(self, x: torch.Tensor):
         return self._run(x, self._inverse)

@@ -64,6 +64,15 @@ def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_n
     hooks = hooks or {}
     refmap_res = DRMNet_model.ds.size
     refmaps, refmasks = [], []
+    marks = []  # hooks["timing"]: per-stage device time (ms) of this call, measured with events on the current stream
+
+    def mark(name):
+        if "timing" in hooks:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
+
+    mark("start")
     for img, nrm, mask in zip(input_imgs, input_normals, masks):
         if erode_kernel_size > 0:
             mask = erode_mask(mask, erode_kernel_size)
@@ -71,6 +80,7 @@ def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_n
         refmaps.append(rm.permute(2, 0, 1))
         refmasks.append(mk)
     B = len(refmaps)
+    mark("refmap_gather")
     batch = {"tag": [f"obj{i}" for i in range(B)], "raw_refmap": torch.stack(refmaps), "raw_refmask": torch.stack(refmasks)}
     c, _, _ = ObsNet_model.get_cond_for_predict(batch, noise=hooks.get("cond_noise"))
     use_ddim = ObsNet_model.ddim_steps is not None
@@ -80,6 +90,7 @@ def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_n
         samples, _ = ObsNet_model.sample_log(cond=c, batch_size=B, ddim=use_ddim, ddim_steps=ObsNet_model.ddim_steps, eta=ObsNet_model.ddim_eta,
                                              **extra, **obs_extra)
     inpaint = ObsNet_model.ds.rescale(ObsNet_model.decode_first_stage(samples))
+    mark("obsnet_sampler")
     LrK, _, illnet_c, refnet_c, _ = DRMNet_model.get_input_for_predict({"tag": batch["tag"], "LrK": inpaint})
     loop_extra = {k: hooks[k] for k in ("noise0", "step_noise") if k in hooks}
     with DRMNet_model.ema_scope():
@@ -87,6 +98,11 @@ def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_n
     Lr0 = DRMNet_model.ds.rescale(DRMNet_model.decode_first_stage(samples)).clip(0)
     if DRMNet_model.refmap_input_scaler is not None:
         Lr0 = Lr0 / DRMNet_model.normalizing_scale[:, None, None, None]
+    mark("drmnet_loop")
+    if marks:
+        marks[-1][1].synchronize()
+        for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
+            hooks["timing"][name] = hooks["timing"].get(name, 0.0) + e0.elapsed_time(e1)
     return Lr0, zK_est, K
 
 

@@ -105,7 +105,9 @@ def test_full_width_sampler_steps_vs_reference(dev, precision):
         e = rel_l2(img.cpu(), g["ddpm_x"][j])
         print(f"full-width ddpm ({precision}) t={t}: {e:.2e}")
         assert e < 1e-4
-        assert rel_l2(x0.cpu(), g["ddpm_pred_x0"][j]) < 2e-3  # x_recon amplifies eps by sqrt(1/abar - 1) ~ 1e8 at t = 999
+        e0 = rel_l2(x0.cpu(), g["ddpm_pred_x0"][j])
+        print(f"full-width ddpm ({precision}) t={t}: pred_x0 {e0:.2e}")
+        assert e0 < 2e-3  # x_recon amplifies eps by sqrt(1/abar - 1) ~ 1e8 at t = 999
     del m
     torch.cuda.empty_cache()
 
@@ -169,4 +171,6 @@ def test_estimate_batch_equals_replicated_estimate(dev):
         assert np.allclose(zK_b[b].cpu().numpy(), zK_1.cpu().numpy(), atol=1e-5, equal_nan=True)
     assert K_b.tolist() == [int(g["K"][0])] * B
     # and the whole batch still matches the reference trace at the north-star tolerance
-    assert rel_l2(Lr0_b[B - 1].cpu(), g["Lr0"]) < 1e-4
+    e_ref = rel_l2(Lr0_b[B - 1].cpu(), g["Lr0"])
+    print(f"estimate_batch row vs reference trace: {e_ref:.2e}")
+    assert e_ref < 2e-5  # (observed 4e-6; the north-star bar is 1e-4)

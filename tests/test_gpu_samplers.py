@@ -100,7 +100,7 @@ def test_ddim_sample_vs_reference_trace(dev, eta, precision):
     x, inter = s.sample(50, cond.shape[0], (3, 16, 16), cond, eta=float(eta), x_T=x_T, verbose=False, noise=noise)
     e = rel_l2(x.cpu(), g["x"])
     print(f"ddim eta={eta}: first step {e1:.2e}, 50 steps {e:.2e}")
-    assert e1 < 2e-5 and e < 2e-4
+    assert e1 < 2e-5 and e < 1e-5  # 50 steps: observed 6.6e-7 (fp32) .. 2e-6
     assert torch.equal(inter["x_inter"][0], x_T)
     # ObsNetDiffusion.sample_log(ddim=True) is the estimate.py entry point (scripts/estimate.py:72-79)
     y, _ = m.sample_log(cond=cond, batch_size=cond.shape[0], ddim=True, ddim_steps=50, eta=float(eta), x_T=x_T, noise=noise)
@@ -115,7 +115,7 @@ def test_ddpm_ancestral_vs_reference_trace(dev):
     e_img = rel_l2(inter["x_inter"][-1].cpu(), g["x_inter"][-1])
     e_x0 = rel_l2(pred_x0.cpu(), g["pred_x0"])
     print(f"ddpm 6 steps: img {e_img:.2e} pred_x0 {e_x0:.2e}")
-    assert e_img < 1e-4 and e_x0 < 1e-4
+    assert e_img < 1e-5 and e_x0 < 1e-5
 
 
 def test_step_dropins_match_reference_named_methods(dev):

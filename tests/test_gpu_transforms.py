@@ -97,3 +97,18 @@ def test_envmap_warp_and_tonemap_vs_reference(dev):
     assert np.abs(hdr2ldr(g["ldr_x"], alpha=0.3, gamma=1.8) - g["ldr_a"]).max() < 2e-6
     with pytest.raises(NotImplementedError):
         mirmap2envmap(mir, (16, 32), reverse_azimuth=False)
+
+
+def test_resize_keeps_its_position_in_the_chain(dev):
+    """dataset/basedataset.py:29-35 applies the maps right to left INCLUDING resize: "log_resize" = log(resize(x)), "resize_log" =
+    resize(log(x)) -- different numbers on an image that actually changes size."""
+    from drmnet_amd.dataset import BaseDataset
+
+    x = torch.exp(torch.randn((2, 3, 32, 32), generator=torch.Generator().manual_seed(8))).to(dev)
+    rs = lambda t: torch.nn.functional.interpolate(t.reshape(-1, 1, 32, 32), size=(16, 16), mode="bilinear", antialias=True, align_corners=False).reshape(2, 3, 16, 16)
+    lg = lambda t: torch.log10(t + 0.1) + 1
+    a = BaseDataset(16, "log_resize").transform(x)
+    b = BaseDataset(16, "resize_log").transform(x)
+    assert tuple(a.shape) == (2, 3, 16, 16)
+    assert torch.allclose(a, lg(rs(x)), rtol=1e-5, atol=2e-6) and torch.allclose(b, rs(lg(x)), rtol=1e-5, atol=2e-6)
+    assert not torch.allclose(a, b, atol=1e-3)

@@ -59,11 +59,12 @@ def test_transform_string_compiles_to_map_chains():
     from drmnet_amd.dataset import BaseDataset
 
     ds = BaseDataset(16, OBS_FUNC, clamp_before_exp=20)
-    assert ds._forward == [("lowerbound", 1e-6), ("norm_log", 0.0), ("unit_to_signed", 0.0)]
+    # forward program = elementwise segments cut at each resize, which keeps its place in the chain (basedataset.py:29-35)
+    assert ds._forward == [[("lowerbound", 1e-6), ("norm_log", 0.0), ("unit_to_signed", 0.0)], "bilinear", []]
     assert ds._inverse == [("signed_to_unit", 0.0), ("denorm_log", 0.0), ("exp10", 20.0)]
-    assert ds._resize_modes == ["bilinear"]
+    assert BaseDataset(16, "log_resizeNEAREST")._forward == [[], "nearest", [("log_p1", 0.0)]]
     d2 = BaseDataset(128, "log", clamp_before_exp=0.0)
-    assert d2._forward == [("log_p1", 0.0)] and d2._inverse == [("exp_m1", math.inf)]
+    assert d2._forward == [[("log_p1", 0.0)]] and d2._inverse == [("exp_m1", math.inf)]
     assert BaseDataset(128, "log", clamp_before_exp=False).clamp_before_exp == 10  # basedataset.py:25
     with pytest.raises(NotImplementedError):
         BaseDataset(16, "gamma2p2")

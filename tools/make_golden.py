@@ -205,6 +205,27 @@ def make_full_nets(oa):
             save(f"full_{name}_{h}x{w}", out=out, t=t, seed=seed, wsum=cs, xsum=synth.checksum(xc), tembsum=synth.checksum(t_emb))
 
 
+def make_full_sizes(oa):
+    """UNetModel / EncoderUNetModel are fully convolutional (openaimodel.py:731-768): any H, W divisible by 2^(levels-1).
+    Full-width outputs at sizes other than the shipped 128x128 / 128x256 (a different ds.size)."""
+    for name, cfg, cls, seed, sizes in (
+        ("illnet", ou.ILLNET_CFG, oa.UNetModel, synth.SEED_ILLNET, ((1, 64, 64), (1, 96, 160), (1, 192, 192), (2, 32, 64))),
+        ("refnet", ou.REFNET_CFG, oa.EncoderUNetModel, synth.SEED_REFNET, ((1, 64, 64), (1, 96, 160), (2, 16, 48))),
+        ("obsnet", ou.OBSNET_CFG, oa.UNetModel, synth.SEED_OBSNET, ((1, 64, 64), (1, 96, 160), (2, 16, 48))),
+    ):
+        m = cls(**cfg).eval()
+        cs = load_rule(m, seed)
+        arrs = {}
+        for n, h, w in sizes:
+            xc, t_emb = full_inputs(n, h, w)
+            t = torch.tensor([7, 981][:n], dtype=torch.long)
+            with torch.no_grad():
+                out = m(xc, t_emb=t_emb) if name == "illnet" else m(xc, t)
+            print(f"  {name} {n}x{h}x{w}: out std {out.std():.4f}")
+            arrs[f"out_{n}x{h}x{w}"] = out
+        save(f"full_{name}_sizes", seed=seed, wsum=cs, t=torch.tensor([7, 981]), **arrs)
+
+
 # ----------------------------------------------------------------------------- samplers
 
 
@@ -223,20 +244,51 @@ def tiny_drmnet(gamma, epsilon, max_timesteps, delta=0.025):
     return m
 
 
-def make_drmnet_loop():
+FULL_CHAIN_T, FULL_CHAIN_EPS = 8, 0.70
+FULL_LOOP_EPS, FULL_LOOP_ILL_SCALE = 0.55, 0.02
+
+
+def full_drmnet(gamma, epsilon, max_timesteps, delta=0.025):
+    """The shipped configs/drmnet/eval_drmnet.yaml networks (IllNet 237.8 M, RefNet 33.3 M parameters by the synth rule)."""
+    DRM, _, _, _ = rh.ref_classes()
+    cfg = rh.load_yaml_params("configs/drmnet/eval_drmnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    cfg.update(gamma=gamma, epsilon=epsilon, max_timesteps=max_timesteps, delta=delta, use_ema=False)
+    m = DRM(**cfg).eval()
+    synth.load_synth(m.illnet_model.diffusion_model, synth.SEED_ILLNET)
+    synth.load_synth(m.refnet_model.diffusion_model, synth.SEED_REFNET)
+    zsd = synth.synth_state_dict([(k, tuple(v.shape)) for k, v in m.illnet_model.z_emb_layer.state_dict().items()], synth.SEED_ZEMB)
+    m.illnet_model.z_emb_layer.load_state_dict(zsd)
+    return m
+
+
+def make_drmnet_loop(full=False):
     import models.drmnet as refdrm
 
-    for tag, (h, w), gamma, eps, T, wscale in (("a", (16, 16), 0.9, 0.78, 17, 10.0), ("b", (16, 32), 0.92, 0.715, 15, 6.0)):
-        m = tiny_drmnet(gamma=gamma, epsilon=eps, max_timesteps=T)
+    cases = (("a", (16, 16), 0.9, 0.78, 17, 10.0), ("b", (16, 32), 0.92, 0.715, 15, 6.0))
+    if full:  # full-width p_sample_loop (models/drmnet.py:782-847) at the config shape: rows converging mid-loop, at the last step, never
+        cases = (("full", (128, 128), 0.9, FULL_LOOP_EPS, 5, 3.0),)
+    for tag, (h, w), gamma, eps, T, wscale in cases:
+        m = (full_drmnet if full else tiny_drmnet)(gamma=gamma, epsilon=eps, max_timesteps=T)
         # spread the per-sample convergence step: amplify the RefNet head and centre it near z0
         head = m.refnet_model.diffusion_model.out[3]
         head_bias = torch.tensor([0.95, 0.9, 0.97, 0.92, 0.05, 0.9])
+        B = 3 if full else 5
+        LrK = synth.synth_refmaps(B, h, w, 99)
+        if full:
+            # random-weight full-width nets: damp the IllNet head (a trained denoiser makes small residual updates; undamped, Lr_k
+            # grows by O(1) per step and every z saturates at the clamp) and centre the RefNet head so that the rows' z_out start
+            # 0.73 away from z0, spread by the (amplified) weight part: K = [never, 2, 3] at epsilon = FULL_LOOP_EPS
+            with torch.no_grad():
+                o = m.illnet_model.diffusion_model.out[2]
+                o.weight.mul_(FULL_LOOP_ILL_SCALE)
+                o.bias.mul_(FULL_LOOP_ILL_SCALE)
+                wpart = m.apply_model(m.refnet_model, LrK, 0, [LrK]) - head.bias
+                head_bias = m.z0 + torch.tensor([-0.3, -0.3, -0.3, -0.3, 0.3, -0.3]) - wscale * wpart.mean(0)
         with torch.no_grad():
             head.weight.mul_(wscale)
             head.bias.copy_(head_bias)
-        B = 5
         g = gen(41)
-        LrK = synth.synth_refmaps(B, h, w, 99)
         noise0 = torch.randn(LrK.shape, generator=g)
         step_noise = torch.randn((T,) + tuple(LrK.shape), generator=g)
         # make one row converge immediately: bias RefNet head so z_out ~ z0 is impossible per-row; instead rely on spread.
@@ -268,6 +320,14 @@ def make_drmnet_loop():
         finally:
             refdrm.torch.randn_like = orig_randn_like
         print(f"  drmnet loop {tag}: K = {K.tolist()}  zK nan rows = {torch.isnan(zK).any(dim=1).tolist()}")
+        if full:
+            dist = torch.stack([(z - m.z0).norm(dim=-1) for z in inter["zk_inter"]])
+            print("  per-step |zk - z0| (rows):", dist.tolist())
+            # inputs and draws are regenerable (synth_refmaps(B, h, w, 99); torch CPU generator seed 41: noise0, step_noise[T])
+            save("drmnet_loop_full", Lr0=Lr0, zK=zK, K=K, z0=m.z0, gamma=gamma, epsilon=eps, delta=0.025, max_timesteps=T, head_w_scale=wscale,
+                 head_bias=head_bias, ill_out_scale=FULL_LOOP_ILL_SCALE, gen_seed=41, input_seed=99, B=B, Lrk_steps=torch.stack(inter["Lrk_inter"][1:])[:, :, :, ::4, ::4],
+                 zk_steps=torch.stack(inter["zk_inter"]), LrK_sum=synth.checksum(LrK), noise_sum=synth.checksum(step_noise))
+            continue
         save(f"drmnet_loop_{tag}", LrK=LrK, noise0=noise0, step_noise=step_noise, Lr0=Lr0, zK=zK, K=K, z0=m.z0,
              gamma=gamma, epsilon=eps, delta=0.025, max_timesteps=T, head_w_scale=wscale, head_bias=head_bias,
              Lrk_steps=torch.stack(inter["Lrk_inter"][1:]), zk_steps=torch.stack(inter["zk_inter"]))
@@ -473,7 +533,7 @@ def make_refmap():
     save("refmap_sample", **out)
 
 
-def make_estimate_chain():
+def make_estimate_chain(full=False):
     """scripts/estimate.py:29-107 + :138-145 end to end on data/sample with 16x16 tiny networks (weights by rule, no
     checkpoint): erosion -> refmap_mask_make -> ObsNet cond transform -> DDIM-50 (eta = 1, noise injected) -> rescale ->
     DRMNet input transform -> DRMNet reverse loop (noise injected) -> rescale / clip / un-normalise -> r0toenvmap -> hdr2ldr.
@@ -487,7 +547,7 @@ def make_estimate_chain():
     sys.path.insert(0, ROOT)
     from drmnet_amd import file_io
 
-    res = 16
+    res = 128 if full else 16
     # Random-weight networks are not denoisers: with the production noise schedule (alpha_bar_T ~ 1e-20) the DDIM iterate
     # explodes to the rescale clamp (1e20) and the rest of the chain is inf/NaN.  The chain fixture therefore uses a gentle
     # schedule and a damped ObsNet head so every stage stays finite and O(1); the schedules proper are pinned elsewhere.
@@ -496,19 +556,23 @@ def make_estimate_chain():
     _, OBS, DDIM, _ = rh.ref_classes()
     ocfg_m = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["model"]["params"]
     ocfg_m.pop("ckpt_path")
-    ocfg_m["unet_config"] = {"target": ocfg_m["unet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
-    ocfg_m.update(image_size=16, use_ema=False, **obs_sched)
+    if not full:
+        ocfg_m["unet_config"] = {"target": ocfg_m["unet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    ocfg_m.update(image_size=res, use_ema=False, **obs_sched)
     obs = OBS(**ocfg_m).eval()
-    synth.load_synth(obs.model.diffusion_model, 21)
+    synth.load_synth(obs.model.diffusion_model, synth.SEED_OBSNET if full else 21)
     with torch.no_grad():
         obs.model.diffusion_model.out[2].weight.mul_(obs_out_scale)
         obs.model.diffusion_model.out[2].bias.mul_(obs_out_scale)
-    drm = tiny_drmnet(gamma=0.9, epsilon=1.0, max_timesteps=17)
+    # full width (the shipped eval configs, 128x128 refmaps): T and epsilon chosen so that the sample converges mid-loop
+    T, epsilon = (FULL_CHAIN_T, FULL_CHAIN_EPS) if full else (17, 1.0)
+    drm = full_drmnet(gamma=0.9, epsilon=epsilon, max_timesteps=T) if full else tiny_drmnet(gamma=0.9, epsilon=1.0, max_timesteps=17)
     head = drm.refnet_model.diffusion_model.out[3]
     head_bias = torch.tensor([0.95, 0.9, 0.97, 0.92, 0.05, 0.9])
-    ill_out_scale = 0.05  # damped IllNet head: the residual updates stay small, the map stays inside the rescale clamp
+    ill_out_scale = 0.02 if full else 0.05  # damped IllNet head: the residual updates stay small, the map stays inside the rescale clamp
+    head_w_scale = 3.0 if full else 10.0
     with torch.no_grad():
-        head.weight.mul_(10.0)
+        head.weight.mul_(head_w_scale)
         head.bias.copy_(head_bias)
         drm.illnet_model.diffusion_model.out[2].weight.mul_(ill_out_scale)
         drm.illnet_model.diffusion_model.out[2].bias.mul_(ill_out_scale)
@@ -553,7 +617,11 @@ def make_estimate_chain():
     inpaint_sample = obs.ds.rescale(obs.decode_first_stage(samples))[0]
     batch = {"tag": ["sample"], "LrK": inpaint_sample[None]}
     LrK, _, illnet_c, refnet_c, _ = drm.get_input_for_predict(batch)
-    T = 17
+    if full:  # centre the (random-weight) RefNet head 0.73 away from z0 on this input, as make_drmnet_loop(full=True) does
+        with torch.no_grad():
+            wpart = drm.apply_model(drm.refnet_model, LrK, 0, refnet_c) - head.bias
+            head_bias = drm.z0 + torch.tensor([-0.3, -0.3, -0.3, -0.3, 0.3, -0.3]) - wpart[0]
+            head.bias.copy_(head_bias)
     noise0 = torch.randn(LrK.shape, generator=g)
     step_noise = torch.randn((T,) + tuple(LrK.shape), generator=g)
     state = {"call": 0, "step": 0}
@@ -568,6 +636,13 @@ def make_estimate_chain():
         return out
 
     refdrm.torch.randn_like = randn_like
+    orig_check = drm.check_convergence
+
+    def check(zk):
+        print("   |zk - z0| =", (zk - drm.z0).norm(dim=-1).tolist())
+        return orig_check(zk)
+
+    drm.check_convergence = check
     try:
         with torch.no_grad():
             samples2, zK_est, K = drm.p_sample_loop(LrK, illnet_c, refnet_c, verbose=False)
@@ -579,10 +654,16 @@ def make_estimate_chain():
     envmap = drm.r0toenvmap(Lr0_sample[None], (drm.image_size, drm.image_size * 2))[0]
     ldr = hdr2ldr(envmap.cpu().numpy())
     print(f"  chain: refmask {int(refmask.sum())}/{res * res}, K = {K.tolist()}, zK = {zK_est[0].tolist()}, env {tuple(envmap.shape)}")
-    save("estimate_chain", refmap=refmap_est, refmask=refmask, cond=c, x_T=x_T, noise=noise, inpaint=inpaint_sample, LrK=LrK, noise0=noise0,
-         step_noise=step_noise, K=K, zK=zK_est, Lr0=Lr0_sample, envmap=envmap, ldr=ldr, head_bias=head_bias, head_w_scale=10.0,
-         gamma=0.9, epsilon=1.0, max_timesteps=17, delta=0.025, obs_out_scale=obs_out_scale, ill_out_scale=ill_out_scale, obs_linear_start=obs_sched["linear_start"],
-         obs_linear_end=obs_sched["linear_end"])
+    common = dict(K=K, zK=zK_est, Lr0=Lr0_sample, envmap=envmap, ldr=ldr, head_bias=head_bias, head_w_scale=head_w_scale, gamma=0.9, epsilon=epsilon,
+                  max_timesteps=T, delta=0.025, obs_out_scale=obs_out_scale, ill_out_scale=ill_out_scale, obs_linear_start=obs_sched["linear_start"],
+                  obs_linear_end=obs_sched["linear_end"])
+    if full:
+        # the draws are regenerable (torch CPU generator, seed 77, in the order x_T, noise[50], noise0, step_noise[T]; the cond's
+        # noise fill is stored: it comes from torch's global generator inside get_cond_for_predict): only outputs are stored
+        save("estimate_chain_full", refmask=refmask, cond=c, inpaint=inpaint_sample, LrK=LrK, gen_seed=77, **common)
+    else:
+        save("estimate_chain", refmap=refmap_est, refmask=refmask, cond=c, x_T=x_T, noise=noise, inpaint=inpaint_sample, LrK=LrK, noise0=noise0,
+             step_noise=step_noise, **common)
     for k_, v_ in (("inpaint", inpaint_sample), ("Lr0", Lr0_sample), ("envmap", envmap)):
         assert torch.isfinite(v_).all(), k_
         print(f"  {k_}: min {float(v_.min()):.3e} max {float(v_.max()):.3e}")
@@ -597,6 +678,9 @@ STEPS = {
     "tiny": lambda oa: make_tiny_nets(oa),
     "blocks": lambda oa: make_blocks(oa),
     "drmnet_loop": lambda oa: make_drmnet_loop(),
+    "drmnet_loop_full": lambda oa: make_drmnet_loop(full=True),
+    "estimate_chain_full": lambda oa: make_estimate_chain(full=True),
+    "full_sizes": lambda oa: make_full_sizes(oa),
     "obsnet_samplers": lambda oa: make_obsnet_samplers(),
     "full": lambda oa: make_full_nets(oa),
     "full_samplers": lambda oa: make_full_samplers(),
