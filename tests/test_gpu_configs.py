@@ -96,7 +96,7 @@ def test_full_width_sampler_steps_vs_reference(dev, precision):
         x, _ = s.sample(50, 1, (3, 128, 256), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, num_steps=k)
         e = rel_l2(x.cpu(), g["ddim_x"][k - 1])
         print(f"full-width ddim ({precision}) after {k} step(s): {e:.2e}")
-        assert e < 1e-4
+        assert e < 1e-5  # observed 1.5e-6
     # ancestral: the device loop walks t = T-1 .. 0 for `start_T` steps from the top only when T == start_T, so the two reference
     # steps (t = 999, 998) are taken through the per-step drop-in p_sample (same fused update kernel)
     img = x_T
@@ -104,10 +104,10 @@ def test_full_width_sampler_steps_vs_reference(dev, precision):
         img, x0 = m.p_sample(img, [cond], torch.full((1,), t, dtype=torch.long, device=dev), clip_denoised=False, return_x0=True, noise=noise[j])
         e = rel_l2(img.cpu(), g["ddpm_x"][j])
         print(f"full-width ddpm ({precision}) t={t}: {e:.2e}")
-        assert e < 1e-4
+        assert e < 2e-6  # observed 2.5e-7
         e0 = rel_l2(x0.cpu(), g["ddpm_pred_x0"][j])
         print(f"full-width ddpm ({precision}) t={t}: pred_x0 {e0:.2e}")
-        assert e0 < 2e-3  # x_recon amplifies eps by sqrt(1/abar - 1) ~ 1e8 at t = 999
+        assert e0 < 1e-5  # observed 1.4e-6 .. 1.7e-6 (x_recon amplifies eps by sqrt(1/abar - 1) at t = 999: both sides alike)
     del m
     torch.cuda.empty_cache()
 
