@@ -95,6 +95,8 @@ struct ConvArgs {
   const float* in_inv = nullptr;       // split-precision path: [N] per-image 2^-k undoing the input staging factor (launch_act_pow2_scale)
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
+// index of the pixel-tile family {TH, TW} that wastes the fewest GEMM rows on an H x W map (ties: the first = larger tile)
+int conv_tile_family(int H, int W, const int (*fam)[2], int n_fam);
 // split-precision (fp16 hi/lo x 3 MFMA, fp32-accurate) variant; a.w = pre-split weights (conv_split.hip)
 int launch_conv_split(const ConvArgs& a, hipStream_t s);
 int conv_split_ksplit(const ConvArgs& a);  // split-K factor the split kernels want for this launch (1 = none)

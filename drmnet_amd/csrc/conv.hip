@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
   // ---- workgroup -> tile (XCD-aware: consecutive logical ids share an XCD's L2, and consecutive logical
   //      ids are the Cout tiles of one pixel tile, then its spatial neighbours)
-  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;  // edge tiles of a map that is not a multiple of the tile are masked
   const int n_tiles = a.Cout / C::BN;
   int logical;
   {
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int img = row / (TH * TW), py = (row / TW) % TH, px = row % TW;
         const int n = n0 + img;
-        if (n < a.N) {
-          const int y = ty0 + py, x = tx0 + px;
+        const int y = ty0 + py, x = tx0 + px;
+        if (n < a.N && y < a.H && x < a.W) {
           float v = acc[i][c][e] + bias;
           if (a.emb) v += a.emb[(size_t)n * a.emb_stride + co];
           const size_t pix = ((size_t)n * a.H + y) * a.W + x;
@@ -268,7 +268,7 @@ static int launch_variant(const ConvArgs& a, hipStream_t s) {
     attr_mask.fetch_or(uint64_t(1) << di->ordinal, std::memory_order_release);
   }
   const int groups = (a.N + C::TN - 1) / C::TN;
-  const long long blocks = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
+  const long long blocks = (long long)groups * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW) * (a.Cout / C::BN);
   DRM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv grid size");
   {
     // algorithmic work: 2 FLOP per MAC on un-padded channels; bytes = input read once + output written once + weights once
@@ -291,14 +291,32 @@ static int dispatch_bn(const ConvArgs& a, hipStream_t s) {
   return launch_variant<TAPS, TH, TW, 4, 1, 1, 1, KC>(a, s);
 }
 
+// Pixel-tile family for an H x W map: the one that wastes the fewest GEMM rows on masked edge pixels (ties: the larger tile).  Maps
+// that are whole multiples of a tile (every shipped configuration) pick exactly what they always did; any other size the reference
+// accepts (openaimodel.py:731-768 is fully convolutional) runs with masked edge tiles.
+int conv_tile_family(int H, int W, const int (*fam)[2], int n_fam) {
+  int best = 0;
+  long long best_area = -1;
+  for (int k = 0; k < n_fam; ++k) {
+    const long long th = fam[k][0], tw = fam[k][1];
+    const long long area = ((H + th - 1) / th) * th * ((W + tw - 1) / tw) * tw;
+    if (best_area < 0 || area < best_area) {
+      best = k;
+      best_area = area;
+    }
+  }
+  return best;
+}
+
 template <int TAPS, int KC>
 static int dispatch_tile(const ConvArgs& a, hipStream_t s) {
-  if (a.H % 8 == 0 && a.W % 16 == 0) return dispatch_bn<TAPS, 8, 16, KC>(a, s);
-  if (a.H % 8 == 0 && a.W % 8 == 0) return dispatch_bn<TAPS, 8, 8, KC>(a, s);
-  if (a.H % 4 == 0 && a.W % 8 == 0) return dispatch_bn<TAPS, 4, 8, KC>(a, s);
-  if (a.H % 4 == 0 && a.W % 4 == 0) return dispatch_bn<TAPS, 4, 4, KC>(a, s);
-  set_error("conv: feature map " + std::to_string(a.H) + "x" + std::to_string(a.W) + " is not a multiple of 4x4");
-  return DRM_ERR_INVALID;
+  static const int fam[4][2] = {{8, 16}, {8, 8}, {4, 8}, {4, 4}};
+  switch (conv_tile_family(a.H, a.W, fam, 4)) {
+    case 0: return dispatch_bn<TAPS, 8, 16, KC>(a, s);
+    case 1: return dispatch_bn<TAPS, 8, 8, KC>(a, s);
+    case 2: return dispatch_bn<TAPS, 4, 8, KC>(a, s);
+    default: return dispatch_bn<TAPS, 4, 4, KC>(a, s);
+  }
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {

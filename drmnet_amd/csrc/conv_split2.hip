@@ -84,7 +84,12 @@ struct S2Cfg {
   static constexpr int OCT = 4;
   static constexpr int A_SLOTS = (HPI * OCT + TPI - 1) / TPI;
   static constexpr bool HPS_FITS = ((TAPS == 1 ? 2 : 1) * 8 * HPS_TRY + R * TPS * 8 * (WN * NT * 32) + TN * (WN * NT * 32)) * 16 <= 160 * 1024;
+#ifdef DRM_EXP_W2
+  // experiment: two independent 4-wave workgroups per CU on 128-pixel x 128-channel tiles need <= 80 KiB each: no plane padding there
+  static constexpr int HPS = (HPS_FITS && !(WM * WN == 4 && TAPS == 9 && TH == 8 && TW == 16 && MT * NT == 4 && NT == 2)) ? HPS_TRY : HP;
+#else
   static constexpr int HPS = HPS_FITS ? HPS_TRY : HP;
+#endif
   static constexpr int A1_F4 = 8 * HPS;                      // one activation tile image
   static constexpr int A_F4 = A_COPIES * A1_F4;  // 1x1: double-buffered (a new tile every step)
   static constexpr int B_F4 = 8 * BN;                            // LDS image of one tap's weight tile (hi and lo planes)
@@ -199,8 +204,10 @@ struct TilePos {
   long long wofs;  // float4 offset of the tile's weights inside one tap/chunk block: its Cout columns (+ its image's own weight set)
 };
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a) {
+// RAG: the map is not a whole number of tiles: edge tiles are masked (loads are bounds-checked in every build; the ragged build also
+// masks the epilogue's stores, residual reads and statistics per pixel).  A separate instantiation, so the shipped shapes' code is untouched.
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && MT * NT >= 8) ? 1 : 2) void conv_split2_kernel(ConvArgs a) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
   extern __shared__ float4 lds[];
   float4* As = lds;                                                   // [hl 2][s 2][h 2][HP]  16-byte entries
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 
   // ---- persistent tile walk.  Logical tile ids are dealt to the 8 XCDs in contiguous ranges (blocks b and b+8 share an
   //      XCD and its L2); inside a range consecutive ids are the Cout tiles of one pixel tile, then spatial neighbours.
-  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  const int tiles_x = RAG ? (a.W + TW - 1) / TW : a.W / TW, tiles_y = RAG ? (a.H + TH - 1) / TH : a.H / TH;
   const int n_tiles = a.Cout / C::BN;
   const int total = ((a.N + C::TN - 1) / C::TN) * tiles_y * tiles_x * n_tiles;
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
@@ -670,6 +677,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       size_t pixb[4];
       int nimg[4];
       bool okg[4];
+      [[maybe_unused]] unsigned okp = 0;  // RAG: validity of the 16 pixels (bit 4g + k) this lane holds of the block row group
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row = (wm * MT + i) * 32 + 8 * g + 4 * h;
@@ -678,12 +686,67 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         const int n = cur.n0 + img;
         okg[g] = n < a.N;
         nimg[g] = okg[g] ? n : a.N - 1;
-        pixb[g] = ((size_t)nimg[g] * a.H + (cur.ty0 + py)) * a.W + (cur.tx0 + px);
+        if constexpr (RAG) {
+          const int y = cur.ty0 + py, x = cur.tx0 + px;
+          okg[g] = okg[g] && y < a.H && x < a.W;  // (the group's first pixel; its other three follow in okp)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (n < a.N && y < a.H && x + k < a.W) okp |= 1u << (4 * g + k);
+          pixb[g] = ((size_t)nimg[g] * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
+        } else {
+          pixb[g] = ((size_t)nimg[g] * a.H + (cur.ty0 + py)) * a.W + (cur.tx0 + px);
+        }
       }
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
         const int col = (wn * NT + c) * 32 + r;
         const int co = cur.co0 + col;
+        if constexpr (RAG) {
+          // masked edge tiles: plain per-element form (residual read, store and statistics under the pixel's own predicate)
+          const bool first = ks == 1;
+          const float bias = (a.bias && first) ? a.bias[co] : 0.f;
+          float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int g = e >> 2, k = e & 3;
+            const bool ok = (okp >> e) & 1u;
+            float v = acc[i][c][e] * ((a.w_inv_img ? a.w_inv_img[nimg[g]] : inv_scale) * (a.in_inv ? a.in_inv[nimg[g]] : 1.0f)) + bias;
+            acc[i][c][e] = 0.f;
+            if (!ok) continue;
+            const size_t pix = pixb[g] + k;
+            if (a.emb && first) v += a.emb[(size_t)nimg[g] * a.emb_stride + co];
+            if (a.res && first) v += a.res[pix * a.Cout + co];
+            if (a.out_nchw) {
+              const size_t hw = (size_t)a.H * a.W;
+              if (co < a.cout_valid) a.out[((size_t)nimg[g] * a.cout_valid + co) * hw + (pix - (size_t)nimg[g] * hw)] = v;
+            } else {
+              out_s[pix * a.Cout + co] = v;
+            }
+            if (e < 8) {
+              s0 += v;
+              q0 += v * v;
+            } else {
+              s1 += v;
+              q1 += v * v;
+            }
+          }
+          if (st) {
+            const int row0 = (wm * MT + i) * 32;
+            if (PPI >= 32) {
+              s0 += s1;
+              q0 += q1;
+            }
+            double* d = lst + ((size_t)(row0 / PPI) * C::BN + col) * 2;
+            atomicAdd(d, (double)s0);
+            atomicAdd(d + 1, (double)q0);
+            if (PPI < 32) {
+              double* d2 = lst + ((size_t)((row0 + 16) / PPI) * C::BN + col) * 2;
+              atomicAdd(d2, (double)s1);
+              atomicAdd(d2 + 1, (double)q1);
+            }
+          }
+          continue;
+        }
         S2_STAMP(20 + 4 * (i * NT + c));  // block (i, c) of the epilogue starts
         // split-K: every split writes its raw partial sums to its own slab (a.out + split * slab); bias / emb / residual and the
         // statistics are applied by the fixed-order reduction that follows (splitk_reduce_kernel)
@@ -800,10 +863,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #endif
 }
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false>
 static int launch_s2(const ConvArgs& a, hipStream_t s) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
-  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
+  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS, RAG>;
+  DRM_REQUIRE(RAG || (a.H % TH == 0 && a.W % TW == 0), "conv tile does not divide the map");
   const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
   static_assert(C::LDS_F4 * 16 <= 160 * 1024, "LDS budget");
   const DeviceInfo* di = device_info();  // fails loudly on anything that is not an MI355X-shaped gfx950 (256 CUs, 160 KiB LDS)
@@ -816,7 +880,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     attr_mask.fetch_or(uint64_t(1) << di->ordinal, std::memory_order_release);
   }
   const int groups = (a.N + C::TN - 1) / C::TN;
-  const long long tiles = (long long)groups * (a.H / TH) * (a.W / TW) * (a.Cout / C::BN);
+  const long long tiles = (long long)groups * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW) * (a.Cout / C::BN);
   DRM_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv grid size");
   // persistent grid: as many workgroups as stay resident (256 CUs x workgroups per CU by LDS), a multiple of 8 (XCDs)
   const int per_cu = std::max(1, std::min((int)(di->lds_per_cu / lds_bytes), 8 / C::NW));
@@ -903,6 +967,12 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     if (a.Cout % 192 == 0 && wgs(256, 192) >= 512) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
   }
   if (a.Cout % 128 == 0 && wgs(256, 128) >= S2_MIN_WIDE_TILES) {
+#ifdef DRM_EXP_W1
+    if constexpr (TAPS == 9 && TH == 16 && TW == 16 && TERMS == 3) return launch_s2<TAPS, TH, TW, 2, 2, 4, 2, RG, TPS, TERMS>(a, s);
+#endif
+#ifdef DRM_EXP_W2
+    if constexpr (TAPS == 9 && TH == 16 && TW == 16 && TERMS == 3) return launch_s2<TAPS, 8, 16, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
+#endif
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
   }
@@ -914,6 +984,18 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS, TERMS>(a, s);
 }
 
+// Maps that are not a whole number of tiles (any H, W the reference accepts other than the shipped sizes): 128-row tiles on 4 waves,
+// 64 or 32 channels wide, in three pixel-tile families, edge tiles masked (RAG instantiations; no split-K, no per-image weights).
+template <int TAPS, int TH, int TW, int TERMS>
+static int dispatch_s2_ragged(const ConvArgs& a, hipStream_t s) {
+  constexpr int TPS = (TAPS == 9) ? 3 : 1;
+  constexpr int RG = (TAPS == 9) ? 2 : 4;
+  if (a.Cout % 64 == 0) return launch_s2<TAPS, TH, TW, 2, 2, 2, 1, RG, TPS, TERMS, true>(a, s);
+  return launch_s2<TAPS, TH, TW, 4, 1, 1, 1, RG, TPS, TERMS, true>(a, s);
+}
+
+static bool s2_exact(const ConvArgs& a) { return a.H % 4 == 0 && a.W % 4 == 0; }
+
 template <int TAPS, int TERMS>
 static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
   if (a.H % 16 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 16, 16, 8, 16, TERMS>(a, s);
@@ -921,15 +1003,20 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
   if (a.H % 8 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 8, 8, 8, 8, TERMS>(a, s);
   if (a.H % 4 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 4, 8, 4, 8, TERMS>(a, s);
   if (a.H % 4 == 0 && a.W % 4 == 0) return dispatch_s2_bn<TAPS, 4, 4, 4, 4, TERMS>(a, s);
-  set_error("conv: feature map " + std::to_string(a.H) + "x" + std::to_string(a.W) + " is not a multiple of 4x4");
-  return DRM_ERR_INVALID;
+  DRM_REQUIRE(a.w_img_stride_f4 == 0 && a.ksplit <= 1, "per-image weights / split-K need a map that is a whole number of tiles");
+  static const int fam[3][2] = {{8, 16}, {8, 8}, {4, 4}};
+  switch (conv_tile_family(a.H, a.W, fam, 3)) {
+    case 0: return dispatch_s2_ragged<TAPS, 8, 16, TERMS>(a, s);
+    case 1: return dispatch_s2_ragged<TAPS, 8, 8, TERMS>(a, s);
+    default: return dispatch_s2_ragged<TAPS, 4, 4, TERMS>(a, s);
+  }
 }
 
 // Split-K factor for a launch (1 = none).  Mirrors dispatch_s2_bn: only the 128-row x 32-channel fallback tiles qualify, when
 // their grid leaves most of the 256 CUs idle and the reduction is long; the caller zero-fills nothing (the launcher does) but
 // must not ask for fused output statistics (partial sums have no statistics) -- engine.hip:run_conv checks this first.
 int conv_split_ksplit(const ConvArgs& a) {
-  if (a.taps != 9 || a.out_nchw) return 1;
+  if (a.taps != 9 || a.out_nchw || !s2_exact(a)) return 1;
   const long long rows = (long long)a.N * a.H * a.W;
   auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
   if (a.Cout % 128 == 0 && wgs(256, 128) >= S2_MIN_WIDE_TILES) return 1;

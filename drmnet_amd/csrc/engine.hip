@@ -477,8 +477,9 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   DRM_REQUIRE(N > 0, "batch size");
   DRM_REQUIRE(Cx + Cc == desc.in_channels, "x/cond channels must sum to in_channels");
   const int down = 1 << (desc.n_levels - 1);
-  DRM_REQUIRE(H % (4 * down) == 0 && W % (4 * down) == 0,
-              "H and W must be multiples of " + std::to_string(4 * down) + " (4x4 minimum feature map at the deepest level)");
+  // any size the reference's fully convolutional forward accepts (openaimodel.py:731-768): every Downsample must see even sizes
+  DRM_REQUIRE(H > 0 && W > 0 && H % down == 0 && W % down == 0,
+              "H and W must be multiples of " + std::to_string(down) + " (2^(levels-1): each of the " + std::to_string(desc.n_levels - 1) + " Downsample layers halves the map)");
   const int n_t = (t_emb != nullptr) + (t != nullptr) + (tf != nullptr);
   if (!ar.dry) {
     if (desc.kind == 0) DRM_REQUIRE(n_t == 1, "timesteps and t_emb cannot be specified at the same time");
