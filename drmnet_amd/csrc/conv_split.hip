@@ -1,4 +1,4 @@
-// Split-precision variant of the fused GroupNorm+SiLU+conv implicit GEMM (see conv.hip for the structure):
+// Split-precision arithmetic of the fused GroupNorm+SiLU+conv implicit GEMM -- entry point + weight pre-split (the kernel: conv_split2.hip):
 // fp32-accurate products on the gfx950 f16 matrix cores.
 //
 // Every fp32 operand x is split as x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant bits together),
@@ -7,9 +7,10 @@
 // Cost per 16-deep K slab: 3 x 32 cycles instead of 8 x 64 cycles of v_mfma_f32_32x32x2_f32  =>  16/3 x the fp32
 // matrix rate, at unchanged HBM traffic (activations stay fp32 in HBM; the split happens once per staged element, in
 // registers, right after the GroupNorm affine + SiLU).
-//   * activations: split unscaled (|x| is O(1) after GroupNorm; tiny elements lose relative precision in the fp16
-//     subnormal range but their absolute error (<= 2^-25) is below the 2^-22 relative error of the O(1) elements);
-//     values are clamped to +-65504 before the split so an outlier saturates instead of becoming inf.
+//   * activations: values a GroupNorm has just normalised are O(1) and are split as they are; an UN-normalised input (skip_connection,
+//     proj_out, stem, attention q / k / v) is first multiplied by a per-image power of two chosen from a rigorous bound of max |x|
+//     (engine.hip raw_input_guard, gn.hip act_pow2_scale_kernel), so that nothing reaches fp16's limit and hi AND lo stay in the normal
+//     range; the epilogue multiplies by the inverse power of two (exact).  A clamp to +-65504 in front of the split is the last resort.
 //   * weights: pre-split at load time after an exact power-of-two scaling that moves max|w| to [8192, 16384), so the lo
 //     halves stay in the fp16 normal range; the epilogue multiplies by the inverse scale (exact).
 // LDS images: A = [hi|lo][slab s][lane-half h][pixel][8 halfs], B = [hi|lo][s][h][cout][8 halfs]; one ds_read_b128 per

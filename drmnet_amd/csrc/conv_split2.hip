@@ -830,8 +830,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && MT * NT >= 8) ? 1 : 2
         S2_STAMP(23 + 4 * (i * NT + c));  // statistics atomics issued
       }
     }
-    if (st) {
-      // fold of this tile's statistics: LDS -> one global fp64 atomic per (image, channel, moment); re-zero for the next tile
+    // The LDS statistics keep accumulating while the workgroup's next tile covers the same images and output channels (on the big maps a
+    // workgroup visits several tiles of one image in a row): the fold -- two barriers and TN * BN * 2 global fp64 atomics -- runs only
+    // when that changes, not once per tile.
+    if (st && (!has_next || nxt.n0 != cur.n0 || nxt.co0 != cur.co0)) {
+      // fold of the accumulated statistics: LDS -> one global fp64 atomic per (image, channel, moment); re-zero for the next tile
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) {

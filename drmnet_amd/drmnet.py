@@ -25,103 +25,63 @@ from .config import instantiate_from_config
 from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma, ZEmbDiffusionWrapper, ema_weights, load_checkpoint
 
 
+# Constructor / YAML keys of the reference (models/drmnet.py:79-240) that steer only training, logging or dataset caches: accepted so that
+# configs/drmnet/*.yaml load unchanged, never read.  Any other unknown key is an error.
+_TRAINING_ONLY = frozenset({
+    "loss_type", "monitor", "scheduler_config", "cond_stage_trainable", "cond_stage_forward", "l_refmap_weight", "l_refcode_weight", "sigma",
+    "train_with_zk_gt", "train_with_zk_gt_switch_epoch", "cache_refmap", "refmap_cache_root", "envmap_dir",
+})
+
+
 class DRMNet(nn.Module):
-    def __init__(
-        self,
-        illnet_config,
-        refnet_config,
-        renderer_config=None,
-        max_timesteps: int = 250,
-        loss_type: str = "l1",
-        ckpt_path: str = None,
-        init_from_ckpt_verbose: bool = True,
-        ignore_keys: List[str] = [],
-        monitor: str = "val/loss",
-        use_ema: bool = True,
-        input_key: str = "LrK",
-        sigma_for_cond_xK: float = 0.0,
-        image_size: int = 128,
-        channels: int = 3,
-        log_every_k: int = 5,
-        parameterization: str = "residual",
-        scheduler_config=None,
-        cond_stage_trainable: bool = False,
-        concat_mode: bool = False,
-        cond_stage_forward: Optional[str] = None,
-        conditioning_key: Optional[str] = None,
-        scale_factor: float = 1.0,
-        scale_by_std: bool = False,
-        l_refmap_weight: float = 1.0,
-        l_refcode_weight: float = 1.0,
-        sigma: float = 0.01,
-        delta: float = 0.0125,
-        gamma: float = 0.9,
-        epsilon: float = 0.001,
-        train_with_zk_gt: bool = False,
-        train_with_zk_gt_switch_epoch: Optional[int] = None,
-        brdf_param_names: List[str] = ["specular"],
-        z0: List[float] = [1.0],
-        model_emb_z: bool = True,
-        emb_z_crossattn: bool = False,
-        refmap_input_scaler: Optional[float] = None,
-        first_stage_config={"target": "ldm.models.autoencoder.IdentityFirstStage"},
-        cond_stage_config="__is_first_stage__",
-        cache_refmap: bool = False,
-        refmap_cache_root: Optional[str] = None,
-        envmap_dir: Optional[str] = None,
-        basis_r0: Optional[torch.Tensor] = None,
-    ):
+    def __init__(self, illnet_config, refnet_config, *, renderer_config=None, max_timesteps: int = 250, ckpt_path: Optional[str] = None,
+                 init_from_ckpt_verbose: bool = True, ignore_keys=(), use_ema: bool = True, input_key: str = "LrK", sigma_for_cond_xK: float = 0.0,
+                 image_size: int = 128, channels: int = 3, log_every_k: int = 5, parameterization: str = "residual", concat_mode: bool = False,
+                 conditioning_key: Optional[str] = None, scale_factor: float = 1.0, scale_by_std: bool = False, delta: float = 0.0125,
+                 gamma: float = 0.9, epsilon: float = 0.001, brdf_param_names=("specular",), z0=(1.0,), model_emb_z: bool = True,
+                 emb_z_crossattn: bool = False, refmap_input_scaler: Optional[float] = None, first_stage_config=None,
+                 cond_stage_config="__is_first_stage__", basis_r0: Optional[torch.Tensor] = None, **training_only):
         super().__init__()
-        assert parameterization in ["residual"], 'currently only supporting "residual"'
+        unknown = sorted(set(training_only) - _TRAINING_ONLY)
+        if unknown:
+            raise TypeError(f"DRMNet: unexpected parameter(s) {unknown}")
+        if parameterization != "residual":
+            raise NotImplementedError('only the "residual" parameterization exists (models/drmnet.py:121)')
+        if not concat_mode:
+            raise AssertionError("This model only supports concat mode")
+        if scale_by_std:
+            raise NotImplementedError("scale_by_std is training-only")
+        if cond_stage_config not in ("__is_first_stage__", "__is_unconditional__"):
+            raise NotImplementedError("a separate cond_stage_config is not on the shipped path")
+        # sampler constants (models/drmnet.py:782-847 reads them per step) and estimate.py's attribute surface
         self.parameterization = parameterization
-        self.log_every_k = log_every_k
-        self.input_key = input_key
-        self.sigma_for_cond_xK = sigma_for_cond_xK
-        self.image_size = image_size
-        self.channels = channels
-        self.max_timesteps = max_timesteps
-        self.brdf_param_names = brdf_param_names
-        self.gamma = gamma
-        self.epsilon = epsilon
-        self._z0 = torch.tensor(z0, dtype=torch.float32)
+        self.max_timesteps, self.gamma, self.epsilon, self.delta = max_timesteps, gamma, epsilon, delta
+        self.log_every_k, self.input_key, self.sigma_for_cond_xK = log_every_k, input_key, sigma_for_cond_xK
+        self.image_size, self.channels, self.scale_factor = image_size, channels, scale_factor
+        self.brdf_param_names = list(brdf_param_names)
+        self.refmap_input_scaler = refmap_input_scaler
+        self.concat_mode = concat_mode
+        self._z0 = torch.tensor(list(z0), dtype=torch.float32)
         self.zdim = len(self._z0)
         self.register_buffer("z0", self._z0)
         self.instantiate_brdf_model(renderer_config, basis_r0)
-
-        assert concat_mode, "This model only supports concat mode"
+        # the two networks behind the reference's wrappers (state_dict keys illnet_model.* / refnet_model.* [+ *_ema.*])
         if conditioning_key is None:
-            conditioning_key = "concat" if concat_mode else "crossattn"
+            conditioning_key = "concat"
         if cond_stage_config == "__is_unconditional__":
             conditioning_key = None
         self.illnet_model = ZEmbDiffusionWrapper(illnet_config, conditioning_key, self.zdim, model_emb_z, emb_z_crossattn)
         self.refnet_model = DiffusionWrapper(refnet_config, conditioning_key)
         self.use_ema = use_ema
-        if self.use_ema:
+        if use_ema:
             self.illnet_model_ema = LitEma(self.illnet_model)
             self.refnet_model_ema = LitEma(self.refnet_model)
-        self.use_scheduler = scheduler_config is not None
-        self.l_refmap_weight = l_refmap_weight
-        self.l_refcode_weight = l_refcode_weight
-        if monitor is not None:
-            self.monitor = monitor
-        self.concat_mode = concat_mode
-        self.cond_stage_trainable = cond_stage_trainable
-        self.scale_by_std = scale_by_std
-        if scale_by_std:
-            raise NotImplementedError("scale_by_std is training-only")
-        self.scale_factor = scale_factor
-        self.first_stage_model = instantiate_from_config(first_stage_config).eval()
+        self.first_stage_model = instantiate_from_config(first_stage_config or {"target": "ldm.models.autoencoder.IdentityFirstStage"}).eval()
         if not isinstance(self.first_stage_model, IdentityFirstStage):
             raise NotImplementedError("only IdentityFirstStage is used by the shipped configs")
-        assert cond_stage_config == "__is_first_stage__" or cond_stage_config == "__is_unconditional__"
         self.cond_stage_model = self.first_stage_model if cond_stage_config == "__is_first_stage__" else None
-        self.cond_stage_forward = cond_stage_forward
         if ckpt_path is not None:
-            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, verbose=init_from_ckpt_verbose)
-        self.loss_type = loss_type
-        self.sigma = sigma
-        self.delta = delta
-        self.refmap_input_scaler = refmap_input_scaler
+            self.init_from_ckpt(ckpt_path, ignore_keys=list(ignore_keys), verbose=init_from_ckpt_verbose)
         self.eval()
         self._samplers = {}  # weight set ("live" / "ema") -> (drm_drmnet handle, signature it was built from)
         self._weight_set = "live"

@@ -22,73 +22,76 @@ from .config import instantiate_from_config
 from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma, ema_weights, load_checkpoint
 
 
-def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
-    """ldm/modules/diffusionmodules/util.py:21-43 ("linear" is what every shipped config uses)."""
-    if schedule == "linear":
-        betas = torch.linspace(linear_start**0.5, linear_end**0.5, n_timestep, dtype=torch.float64) ** 2
-    elif schedule == "sqrt_linear":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
-    elif schedule == "sqrt":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
-    else:
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2):
+    """The beta tables of ldm/modules/diffusionmodules/util.py:21-43 that are spaced between two end points, in fp64: "linear" (every shipped
+    config) is linear in sqrt(beta), "sqrt_linear" in beta, "sqrt" is the square root of a linear ramp.  (The cosine table is training-side.)"""
+    def ramp(lo, hi):
+        return torch.linspace(lo, hi, n_timestep, dtype=torch.float64)
+
+    tables = {"linear": lambda: ramp(linear_start**0.5, linear_end**0.5) ** 2, "sqrt_linear": lambda: ramp(linear_start, linear_end),
+              "sqrt": lambda: ramp(linear_start, linear_end) ** 0.5}
+    if schedule not in tables:
         raise ValueError(f"schedule '{schedule}' unknown.")
-    return betas.numpy()
+    return tables[schedule]().numpy()
 
 
 def extract_into_tensor(a, t, x_shape):
-    b, *_ = t.shape
-    out = a.gather(-1, t)
-    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+    """Per-sample table entries a[t] shaped to broadcast against x (util.py:96-99)."""
+    return a[t].reshape((t.shape[0],) + (1,) * (len(x_shape) - 1))
+
+
+# Constructor / YAML keys of the reference that steer only training, logging or the out-of-scope renderers (ldm/models/diffusion/ddpm.py:60-135,
+# :442-512; models/obsnet.py:38-137).  They are ACCEPTED, so configs/**.yaml and reference-style constructor calls load unchanged, and never
+# read: nothing on the sampling path depends on them.  Any other unknown key is an error.
+_TRAINING_ONLY = frozenset({
+    "loss_type", "monitor", "original_elbo_weight", "l_simple_weight", "scheduler_config", "use_positional_encodings", "logvar_init", "cosine_s",
+    "first_stage_key", "cond_stage_trainable", "masked_loss", "obj_img_key", "cache_data", "refmap_cache_root", "objimg_cache_root", "envmap_dir",
+    "img_renderer_config",
+})
+
+
+def _drop_training_only(kwargs: dict, who: str) -> None:
+    unknown = sorted(set(kwargs) - _TRAINING_ONLY)
+    if unknown:
+        raise TypeError(f"{who}: unexpected parameter(s) {unknown}")
 
 
 class DDPM(nn.Module):
-    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", loss_type="l2", ckpt_path=None, ignore_keys=[],
-                 load_only_unet=False, monitor="val/loss", use_ema=True, first_stage_key="image", image_size=256, channels=3, log_every_t=100,
-                 clip_denoised=True, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3, given_betas=None, original_elbo_weight=0.0,
-                 v_posterior=0.0, l_simple_weight=1.0, conditioning_key=None, parameterization="eps", scheduler_config=None,
-                 use_positional_encodings=False, learn_logvar=False, logvar_init=0.0):
+    """The noise schedule + the wrapped eps-network (ddpm.py:59-231), inference half."""
+
+    def __init__(self, unet_config, *, timesteps=1000, beta_schedule="linear", ckpt_path=None, ignore_keys=(), load_only_unet=False, use_ema=True,
+                 image_size=256, channels=3, log_every_t=100, clip_denoised=True, linear_start=1e-4, linear_end=2e-2, given_betas=None,
+                 v_posterior=0.0, conditioning_key=None, parameterization="eps", learn_logvar=False, **training_only):
         super().__init__()
-        assert parameterization in ["eps", "x0"], 'currently only supporting "eps" and "x0"'
+        _drop_training_only(training_only, type(self).__name__)
         if parameterization != "eps":
-            raise NotImplementedError("only eps-prediction is on the shipped path")
+            raise NotImplementedError('only the "eps" parameterization is on the shipped path')
+        if learn_logvar:
+            raise NotImplementedError("learn_logvar is training-only")
         self.parameterization = parameterization
+        self.image_size, self.channels = image_size, channels
+        self.clip_denoised, self.log_every_t, self.v_posterior = clip_denoised, log_every_t, v_posterior
         self.cond_stage_model = None
-        self.clip_denoised = clip_denoised
-        self.log_every_t = log_every_t
-        self.first_stage_key = first_stage_key
-        self.image_size = image_size
-        self.channels = channels
-        self.use_positional_encodings = use_positional_encodings
         self.model = DiffusionWrapper(unet_config, conditioning_key)
         self._weight_set = "live"
         self.use_ema = use_ema
-        if self.use_ema:
+        if use_ema:
             self.model_ema = LitEma(self.model)
-        self.v_posterior = v_posterior
-        self.original_elbo_weight = original_elbo_weight
-        self.l_simple_weight = l_simple_weight
-        if monitor is not None:
-            self.monitor = monitor
         if ckpt_path is not None:
-            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, only_model=load_only_unet)
-        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
-                               linear_end=linear_end, cosine_s=cosine_s)
-        self.loss_type = loss_type
-        self.learn_logvar = learn_logvar
-        if learn_logvar:
-            raise NotImplementedError("learn_logvar is training-only")
+            self.init_from_ckpt(ckpt_path, ignore_keys=list(ignore_keys), only_model=load_only_unet)
+        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start, linear_end=linear_end)
 
     @property
     def device(self):
         return self.betas.device
 
-    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4, linear_end=2e-2):
         """ldm/models/diffusion/ddpm.py:137-187: every table of the forward / posterior process is computed in fp64 numpy from the
         betas and registered as an fp32 buffer -- same names, same order, so ``state_dict()`` matches the reference's checkpoints
         (tests/golden/ddpm_schedule.npz pins the values bit for bit).  abar_t = prod(1 - beta); posterior q(x_{t-1} | x_t, x_0)
         has variance beta_t (1 - abar_{t-1}) / (1 - abar_t) (mixed with beta_t by v_posterior) and mean coefficients
         beta_t sqrt(abar_{t-1}) / (1 - abar_t) on x_0 and (1 - abar_{t-1}) sqrt(alpha_t) / (1 - abar_t) on x_t."""
-        beta = given_betas if given_betas is not None else make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end, cosine_s)
+        beta = given_betas if given_betas is not None else make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end)
         (n_steps,) = beta.shape
         self.num_timesteps = int(n_steps)
         self.linear_start, self.linear_end = linear_start, linear_end
@@ -137,43 +140,30 @@ class DDPM(nn.Module):
 
 
 class LatentDiffusion(DDPM):
-    def __init__(self, first_stage_config, cond_stage_config, num_timesteps_cond=None, cond_stage_key="image", cond_stage_trainable=False,
-                 concat_mode=True, cond_stage_forward=None, conditioning_key=None, scale_factor=1.0, scale_by_std=False, *args, **kwargs):
-        self.num_timesteps_cond = 1 if num_timesteps_cond is None else num_timesteps_cond
-        self.scale_by_std = scale_by_std
-        assert self.num_timesteps_cond <= kwargs["timesteps"]
+    """DDPM + conditioning by concatenation behind an identity first stage (ddpm.py:439-512), inference half."""
+
+    def __init__(self, first_stage_config, cond_stage_config, *, num_timesteps_cond=None, cond_stage_key="image", concat_mode=True, cond_stage_forward=None,
+                 conditioning_key=None, scale_factor=1.0, scale_by_std=False, ckpt_path=None, ignore_keys=(), **ddpm_kwargs):
+        if scale_by_std:
+            raise NotImplementedError("scale_by_std is training-only")
+        if (num_timesteps_cond or 1) != 1:
+            raise NotImplementedError("num_timesteps_cond > 1 (shortened conditioning schedule) is not on the shipped path")
+        if cond_stage_config not in ("__is_first_stage__", "__is_unconditional__"):
+            raise NotImplementedError("a separate cond_stage_config is not on the shipped path")
         if conditioning_key is None:
             conditioning_key = "concat" if concat_mode else "crossattn"
         if cond_stage_config == "__is_unconditional__":
             conditioning_key = None
-        ckpt_path = kwargs.pop("ckpt_path", None)
-        ignore_keys = kwargs.pop("ignore_keys", [])
-        super().__init__(conditioning_key=conditioning_key, *args, **kwargs)
-        self.concat_mode = concat_mode
-        self.cond_stage_trainable = cond_stage_trainable
-        self.cond_stage_key = cond_stage_key
-        self.num_downs = 0
-        if scale_by_std:
-            raise NotImplementedError("scale_by_std is training-only")
-        self.scale_factor = scale_factor
+        super().__init__(conditioning_key=conditioning_key, **ddpm_kwargs)  # (the checkpoint is read below, once the whole module exists)
+        self.num_timesteps_cond = 1
+        self.concat_mode, self.cond_stage_key, self.cond_stage_forward, self.scale_factor = concat_mode, cond_stage_key, cond_stage_forward, scale_factor
         self.first_stage_model = instantiate_from_config(first_stage_config).eval()
         if not isinstance(self.first_stage_model, IdentityFirstStage):
             raise NotImplementedError("only IdentityFirstStage is used by the shipped configs")
-        if cond_stage_config == "__is_first_stage__":
-            self.cond_stage_model = self.first_stage_model
-        elif cond_stage_config == "__is_unconditional__":
-            self.cond_stage_model = None
-        else:
-            raise NotImplementedError("separate cond_stage_config is not on the shipped path")
-        self.cond_stage_forward = cond_stage_forward
-        self.clip_denoised = False
-        self.shorten_cond_schedule = self.num_timesteps_cond > 1
-        if self.shorten_cond_schedule:
-            raise NotImplementedError("num_timesteps_cond > 1 is not on the shipped path")
-        self.restarted_from_ckpt = False
+        self.cond_stage_model = self.first_stage_model if cond_stage_config == "__is_first_stage__" else None
+        self.clip_denoised = False  # (ddpm.py:492: LatentDiffusion overrides the DDPM default)
         if ckpt_path is not None:
-            self.init_from_ckpt(ckpt_path, ignore_keys)
-            self.restarted_from_ckpt = True
+            self.init_from_ckpt(ckpt_path, list(ignore_keys))
         self._ws = _lib.Workspace()
 
     def set_precision(self, precision: str):
@@ -279,28 +269,16 @@ class LatentDiffusion(DDPM):
 class ObsNetDiffusion(LatentDiffusion):
     """inpainting class (models/obsnet.py:35)."""
 
-    def __init__(self, renderer_config=None, img_renderer_config=None, num_timesteps_cond=None, cond_stage_key="image", padding_mode="noise",
-                 cond_stage_trainable=False, concat_mode=True, cond_stage_forward=None, conditioning_key=None, scale_factor=1.0,
-                 scale_by_std=False, ddim_steps: Optional[int] = None, ddim_eta: float = 1.0, masked_loss: bool = True,
-                 noisy_observe: float = 0.0, obj_img_key=None, init_from_ckpt_verbose=True, cache_data: bool = False, refmap_cache_root=None,
-                 objimg_cache_root=None, envmap_dir=None, first_stage_config={"target": "ldm.models.autoencoder.IdentityFirstStage"},
-                 cond_stage_config="__is_first_stage__", *args, **kwargs):
-        ckpt_path = kwargs.pop("ckpt_path", None)
-        ignore_keys = kwargs.pop("ignore_keys", [])
-        super().__init__(first_stage_config, cond_stage_config, num_timesteps_cond=num_timesteps_cond, cond_stage_key=cond_stage_key,
-                         cond_stage_trainable=cond_stage_trainable, concat_mode=concat_mode, cond_stage_forward=cond_stage_forward,
-                         conditioning_key=conditioning_key, scale_factor=scale_factor, scale_by_std=scale_by_std, *args, **kwargs)
+    def __init__(self, *, renderer_config=None, padding_mode="noise", ddim_steps: Optional[int] = None, ddim_eta: float = 1.0, noisy_observe: float = 0.0,
+                 init_from_ckpt_verbose=True, first_stage_config=None, cond_stage_config="__is_first_stage__", ckpt_path=None, ignore_keys=(), **kwargs):
+        if first_stage_config is None:
+            first_stage_config = {"target": "ldm.models.autoencoder.IdentityFirstStage"}
+        super().__init__(first_stage_config, cond_stage_config, **kwargs)
         self.renderer = instantiate_from_config(renderer_config) if renderer_config is not None else None
-        self.padding_mode = padding_mode
-        self.restarted_from_ckpt = False
+        self.padding_mode, self.noisy_observe = padding_mode, noisy_observe
+        self.ddim_steps, self.ddim_eta = ddim_steps, ddim_eta
         if ckpt_path is not None:
-            self.init_from_ckpt(ckpt_path, ignore_keys, verbose=init_from_ckpt_verbose)
-            self.restarted_from_ckpt = True
-        self.masked_loss = masked_loss
-        self.noisy_observe = noisy_observe
-        self.obj_img_key = obj_img_key
-        self.ddim_steps = ddim_steps
-        self.ddim_eta = ddim_eta
+            self.init_from_ckpt(ckpt_path, list(ignore_keys), verbose=init_from_ckpt_verbose)
         self.eval()
 
     @torch.no_grad()

@@ -11,10 +11,10 @@ cd "$ROOT"
 python3 bench.py > $OUT/${tag}_bench_f16x3.log 2>&1
 grep "^{\"metric\"" $OUT/${tag}_bench_f16x3.log | tail -1 > $OUT/${tag}_bench_f16x3.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-check --no-strict-fp32 > $OUT/${tag}_bench_f16x3_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-check --no-strict-fp32 --no-secondary > $OUT/${tag}_bench_f16x3_under_rocprof.log 2>&1
 grep "^{\"metric\"" $OUT/${tag}_bench_f16x3_under_rocprof.log | tail -1 > $OUT/${tag}_bench_f16x3_under_rocprof.json
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-parity-check --no-strict-fp32 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-parity-check --no-strict-fp32 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-parity-check --no-strict-fp32 --no-secondary > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-parity-check --no-strict-fp32 --no-secondary > $OUT/pmc_write.log 2>&1
 cd $ROOT
 python3 - "$tag" <<'PY'
 import sqlite3, glob, json, sys, csv, collections
