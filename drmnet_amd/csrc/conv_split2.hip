@@ -84,12 +84,7 @@ struct S2Cfg {
   static constexpr int OCT = 4;
   static constexpr int A_SLOTS = (HPI * OCT + TPI - 1) / TPI;
   static constexpr bool HPS_FITS = ((TAPS == 1 ? 2 : 1) * 8 * HPS_TRY + R * TPS * 8 * (WN * NT * 32) + TN * (WN * NT * 32)) * 16 <= 160 * 1024;
-#ifdef DRM_EXP_W2
-  // experiment: two independent 4-wave workgroups per CU on 128-pixel x 128-channel tiles need <= 80 KiB each: no plane padding there
-  static constexpr int HPS = (HPS_FITS && !(WM * WN == 4 && TAPS == 9 && TH == 8 && TW == 16 && MT * NT == 4 && NT == 2)) ? HPS_TRY : HP;
-#else
   static constexpr int HPS = HPS_FITS ? HPS_TRY : HP;
-#endif
   static constexpr int A1_F4 = 8 * HPS;                      // one activation tile image
   static constexpr int A_F4 = A_COPIES * A1_F4;  // 1x1: double-buffered (a new tile every step)
   static constexpr int B_F4 = 8 * BN;                            // LDS image of one tap's weight tile (hi and lo planes)
@@ -206,12 +201,9 @@ struct TilePos {
 
 // RAG: the map is not a whole number of tiles: edge tiles are masked (loads are bounds-checked in every build; the ragged build also
 // masks the epilogue's stores, residual reads and statistics per pixel).  A separate instantiation, so the shipped shapes' code is untouched.
-// PIPE (3x3, 8 waves, 256 x 128 tiles): the slab-pipelined main loop -- see "slab pipeline" below.
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false, bool PIPE = false>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && MT * NT >= 8) ? 1 : 2) void conv_split2_kernel(ConvArgs a) {
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
-  static_assert(!PIPE || (TAPS == 9 && TPS == 3 && R == 2 && TERMS == 3 && !RAG && C::TN == 1 && C::NW == 8 && C::BN == 128),
-                "the slab pipeline is built for the 16x16-pixel x 128-channel tile on 8 waves");
   extern __shared__ float4 lds[];
   float4* As = lds;                                                   // [hl 2][s 2][h 2][HP]  16-byte entries
   float4* Bs = lds + C::A_F4;                                         // R x TPS x [hl 2][s 2][h 2][BN]
@@ -431,138 +423,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && MT * NT >= 8) ? 1 : 2
   // ---- prologue: R-1 weight groups in flight (they may already belong to the next tile when a tile has < R-1 groups),
   //      first activation tile staged
   int gseq = 0;  // groups issued so far
-  // ---- slab pipeline (PIPE).  A 32-channel chunk is two 16-channel SLABS (the two k-steps of its MFMAs); the LDS activation image keeps
-  // them in separate planes.  The main loop runs slab-major -- all nine taps of slab 0, then all nine taps of slab 1, in six steps of three
-  // HALF-taps (one slab of one tap's weights: [hi|lo][h][BN], 8 KB) -- so that while one slab's planes are read by the MFMAs the OTHER
-  // slab's planes are re-staged with the next chunk's channels, a few VALU instructions at a time between the MFMAs: the chunk-end phase of
-  // the classic loop (barrier, staging of a whole 32-channel tile on all eight waves with the matrix pipe idle, barrier) does not exist.
-  // The weight ring is the same LDS as the classic ring of two three-tap groups, cut into four groups of three half-taps, three steps
-  // ahead.  Per chunk, steps k = 0..5 (k = 3 * slab + tap row):
-  //   every k      the DMA of the group three steps ahead (1 KiB per wave and half-tap) at the first hook
-  //   k = 0, 3     stage slot 0 of the slab loaded two steps ago into the planes the MFMAs left at the last barrier
-  //   k = 1, 4     stage its slot 1, then request the same slab of the NEXT chunk (or of the next tile's first chunk)
-  //   end of step  counted wait for the next group (younger: the DMAs of this and the previous step, + the 8 activation loads when they
-  //                were requested in this or the previous step), lgkmcnt(0), ONE barrier
-  constexpr int PG_F4 = C::G_F4 / 2;   // three half-taps
-  constexpr int HB_F4 = 4 * C::BN;     // one half-tap
-  constexpr int PA_SLOTS = (C::HPI * 2 + C::NTHR - 1) / C::NTHR;  // (pixel, octet-of-the-slab) pairs per thread: 648 / 512 -> 2
-  constexpr int PA_CNT = 2 * PA_SLOTS + 4;                          // vector loads per slab request
-  [[maybe_unused]] f32x4 preg[PA_SLOTS][2];
-  [[maybe_unused]] unsigned pvalid = 0;
-  [[maybe_unused]] unsigned pvoff[2] = {0, 0};
-  [[maybe_unused]] auto p_request = [&](const TilePos& tp, int chunk, int sl, int part) {  // part 0: the pixel slots, part 1: scale / shift
-    const int c = (chunk0 + chunk) * C::KC + sl * 16;
-    const float* src;
-    int Cs, coff, up;
-    if (c < a.C0) {
-      src = a.src0; Cs = a.ld0 ? a.ld0 : a.C0; coff = c; up = a.up0;
-    } else {
-      src = a.src1; Cs = a.C1; coff = c - a.C0; up = 0;
-    }
-    const int Hs = up ? (a.H >> 1) : a.H, Ws = up ? (a.W >> 1) : a.W;
-    const int nc = tp.n0 < a.N ? tp.n0 : a.N - 1;
-    const int o2 = tid & 1;
-    if (part == 0) {
-      pvalid = 0;
-#pragma unroll
-      for (int j = 0; j < PA_SLOTS; ++j) {
-        const int lidx = tid + C::NTHR * j;
-        const int hpl = lidx >> 1;
-        const int hy = hpl / C::WT, hx = hpl % C::WT;
-        const int y = tp.ty0 + hy - C::HALO, x = tp.tx0 + hx - C::HALO;
-        const bool ok = (lidx < C::HPI * 2) && (tp.n0 < a.N) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
-        const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
-        const int ys = up ? (yc >> 1) : yc, xs = up ? (xc >> 1) : xc;
-        const size_t pix = ((size_t)nc * Hs + ys) * Ws + xs;
-        gload16x2(preg[j][0], preg[j][1], src + pix * Cs + coff + 8 * o2);
-        if (ok) pvalid |= 1u << j;
-      }
-    } else {
-      const float* gs = has_gn ? a.gn_scale + (size_t)nc * Ctot + c + 8 * o2 : a.src0;
-      const float* gb = has_gn ? a.gn_shift + (size_t)nc * Ctot + c + 8 * o2 : a.src0;
-      gload16x2(sc[0], sc[1], gs);
-      gload16x2(sh[0], sh[1], gb);
-    }
-  };
-  [[maybe_unused]] auto p_tie = [&]() {
-#pragma unroll
-    for (int j = 0; j < PA_SLOTS; ++j) tie_regs(preg[j][0], preg[j][1]);
-    tie_regs(sc[0], sc[1]);
-    tie_regs(sh[0], sh[1]);
-  };
-  [[maybe_unused]] auto p_stage = [&](int sl, int j) {  // slot j of the requested slab -> planes (sl, octet) of the LDS image
-    const int lidx = tid + C::NTHR * j;
-    if (lidx < C::HPI * 2) {
-      F4H8b hi, lo;
-      float v[8] = {preg[j][0].x, preg[j][0].y, preg[j][0].z, preg[j][0].w, preg[j][1].x, preg[j][1].y, preg[j][1].z, preg[j][1].w};
-      if (has_gn) {
-        const float s8[8] = {sc[0].x, sc[0].y, sc[0].z, sc[0].w, sc[1].x, sc[1].y, sc[1].z, sc[1].w};
-        const float b8[8] = {sh[0].x, sh[0].y, sh[0].z, sh[0].w, sh[1].x, sh[1].y, sh[1].z, sh[1].w};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = v[k] * s8[k] + b8[k];
-      }
-      if (a.silu) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = silu2(v[k]);
-      }
-      const bool ok = (pvalid >> j) & 1u;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        _Float16 hh, ll;
-        split2(ok ? v[k] : 0.f, hh, ll);
-        hi.h8[k] = hh;
-        lo.h8[k] = ll;
-      }
-      const int hpl = lidx >> 1;
-      const int pixel = (hpl / C::WT) * C::WTP + (hpl % C::WT);
-      const int oct = sl * 2 + (tid & 1);
-      As[oct * C::HPS + pixel] = hi.f4;
-      As[(4 + oct) * C::HPS + pixel] = lo.f4;
-    }
-  };
-  // the three 1-KiB DMA instructions of pipeline group `pgi` of a tile (tile-local index; group = (chunk, slab, tap row)) into ring slot seq % 4
-  [[maybe_unused]] auto p_issue = [&](int seq, int pgi, long long co0) {
-    const int chunk = pgi / 6, k6 = pgi - chunk * 6;
-    const int sl = k6 / 3, g = k6 - sl * 3;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int tap = g * 3 + u;
-      const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)tap * nch_all + chunk0 + chunk) * 8) * a.Cout + co0;
-      glds16s(wp, pvoff[0] + (unsigned)sl * (pvoff[1] - pvoff[0]), lds_bs + (unsigned)((seq & 3) * PG_F4 + u * HB_F4 + wave * 64) * 16u);
-    }
-  };
-  if constexpr (PIPE) {
-    // per-lane source offset of this wave's piece of a half-tap: LDS plane q = hl * 2 + h <- global plane hl * 4 + slab * 2 + h
-    const int idx = wave * 64 + lane, q = idx / C::BN, col = idx % C::BN;
-    pvoff[0] = (unsigned)(((q >> 1) * 4 + (q & 1)) * a.Cout + col) * 16u;
-    pvoff[1] = (unsigned)(((q >> 1) * 4 + 2 + (q & 1)) * a.Cout + col) * 16u;
-    const int PNG = nchunks * 6;
-    int k2 = k_tile;
-    TilePos tp = cur;
-    int gi = 0;
-#pragma unroll
-    for (int G = 0; G < 3; ++G) {
-      if (gi >= PNG) {
-        gi = 0;
-        if (k2 + J < x_count) {
-          k2 += J;
-          tp = decode(x_start + k2);
-        }
-      }
-      p_issue(gseq++, gi++, tp.wofs);
-    }
-    p_request(cur, 0, 0, 0);
-    p_request(cur, 0, 0, 1);
-    wait_vmcnt<0>();
-    p_tie();
-#pragma unroll
-    for (int j = 0; j < PA_SLOTS; ++j) p_stage(0, j);
-    p_request(cur, 0, 1, 0);  // slab 1 of the first chunk: staged in steps 0 and 1 like every later one
-    p_request(cur, 0, 1, 1);
-    wait_vmcnt<0>();          // (once per workgroup: makes the counted waits of the first steps hold trivially)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  } else {
   {
     int k2 = k_tile;
     TilePos tp = cur;
@@ -588,7 +448,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && MT * NT >= 8) ? 1 : 2
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  }  // (classic prologue)
 
   // Per step (group g of chunk c of the current tile; g is a compile-time constant):
   //   (1) issue the DMA of the group R-1 steps ahead into the slot consumed one step ago (it may belong to the NEXT tile),
@@ -669,80 +528,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && MT * NT >= 8) ? 1 : 2
       issue_G(gseq, gi, co0);
       ++gseq;
     };
-    if constexpr (PIPE) {
-      const int PNG = nchunks * 6;
-      for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool more = chunk + 1 < nchunks;
-        const bool a_next = more || has_next;  // a next chunk exists: its slabs are requested in steps 1 and 4 and staged two steps later
-        static_for(std::make_integer_sequence<int, 6>{}, [&](auto kc) {
-          constexpr int k6 = decltype(kc)::value;
-          constexpr int sl = k6 / 3, g = k6 % 3;
-          int d_gi = chunk * 6 + k6 + 3;
-          long long d_co0 = cur.wofs;
-          if (d_gi >= PNG) {
-            d_gi -= PNG;
-            if (d_gi >= PNG) d_gi %= PNG;
-            d_co0 = nxt.wofs;
-          }
-          const int d_seq = gseq++;
-          // what is staged in this half of the chunk: k6 < 3 -> slab 1 of THIS chunk (requested in step 4 of the previous one, or by the
-          // prologue); k6 >= 3 -> slab 0 of the NEXT chunk (requested in step 1)
-          const bool stage_now = (k6 < 3) || a_next;
-          const float4* Bg = Bs + (step & 3) * PG_F4;
-#pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            const int tap = g * 3 + u;
-            const int tapoff = (tap / 3) * C::WTP + (tap % 3);
-            const int seg = sl * 2 + h;
-            F4H8b ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-              ah[i].f4 = As[seg * C::HPS + a_base[i] + tapoff];
-              al[i].f4 = As[(4 + seg) * C::HPS + a_base[i] + tapoff];
-            }
-#pragma unroll
-            for (int c = 0; c < NT; ++c) {
-              bh[c].f4 = Bg[u * HB_F4 + h * C::BN + b_base[c]];
-              bl[c].f4 = Bg[u * HB_F4 + (2 + h) * C::BN + b_base[c]];
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int c = 0; c < NT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-            // side work of the step goes out here, behind MFMAs that keep the pipe busy
-            __builtin_amdgcn_sched_barrier(0);
-            if (u == 0) p_issue(d_seq, d_gi, d_co0);
-            if (g == 0 && u == 1 && stage_now) {
-              wait_vmcnt<6>();  // the slab requested two steps ago; younger: the DMAs of the previous and of this step
-              p_tie();
-              p_stage(sl ^ 1, 0);
-            }
-            if (g == 1 && u == 0 && stage_now) {
-#pragma unroll
-              for (int j = 1; j < PA_SLOTS; ++j) p_stage(sl ^ 1, j);
-            }
-            if (g == 1 && u >= 1 && a_next) {  // request the slab the MFMAs are reading now, of the chunk after: it is staged three steps from here
-              if (more) p_request(cur, chunk + 1, sl, u - 1);
-              else p_request(nxt, 0, sl, u - 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int c = 0; c < NT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int c = 0; c < NT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
-          }
-          ++step;
-          if (g != 0 && a_next) wait_vmcnt<6 + PA_CNT>();
-          else wait_vmcnt<6>();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        });
-      }
-    } else if constexpr (TAPS == 1) {
+    if constexpr (TAPS == 1) {
       // 1x1 pipeline: one 32-channel chunk per step, activation tiles double-buffered in LDS.  areg always holds the
       // NEXT step's activations (requested one step ago).  "Side work" of a step = stage them into the other LDS buffer,
       // request the step after next, issue the weight DMA R-1 steps ahead; the activation request goes out BEFORE the
@@ -1075,10 +861,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && MT * NT >= 8) ? 1 : 2
 #endif
 }
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false, bool PIPE = false>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false>
 static int launch_s2(const ConvArgs& a, hipStream_t s) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
-  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS, RAG, PIPE>;
+  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS, RAG>;
   DRM_REQUIRE(RAG || (a.H % TH == 0 && a.W % TW == 0), "conv tile does not divide the map");
   const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
   static_assert(C::LDS_F4 * 16 <= 160 * 1024, "LDS budget");
@@ -1179,15 +965,6 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     if (a.Cout % 192 == 0 && wgs(256, 192) >= 512) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
   }
   if (a.Cout % 128 == 0 && wgs(256, 128) >= S2_MIN_WIDE_TILES) {
-#ifdef DRM_EXP_W1
-    if constexpr (TAPS == 9 && TH == 16 && TW == 16 && TERMS == 3) return launch_s2<TAPS, TH, TW, 2, 2, 4, 2, RG, TPS, TERMS>(a, s);
-#endif
-#ifdef DRM_EXP_W2
-    if constexpr (TAPS == 9 && TH == 16 && TW == 16 && TERMS == 3) return launch_s2<TAPS, 8, 16, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
-#endif
-#ifdef DRM_EXP_PIPE
-    if constexpr (TAPS == 9 && TH == 16 && TW == 16 && TERMS == 3) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS, false, true>(a, s);
-#endif
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
   }
