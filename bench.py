@@ -356,7 +356,7 @@ def strict_fp32_pass(args, model, dev, L, _lib):
     ach = tf[0] / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else None
     return {"value": round(args.batch * n / dt, 3), "unit": "denoise steps/sec (samples x steps / s)", "steps": n, "ms_per_step": round(dt / n * 1e3, 3),
             "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)",
-            "roofline": None if ach is None else {"bound": "mfma", "kernel": "conv_igemm_kernel<9,...>", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+            "roofline": None if ach is None else {"bound": "mfma", "kernel": "conv_split2_kernel<9,...,TERMS=0> (the same LDS-DMA pipeline kernel on fp32 operands, v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(tm[0] / max(tn[0], 1), 4)}}
 
 
@@ -541,7 +541,7 @@ def main():
             peak = F16_MFMA_PEAK_TFLOPS if (split or plain) else FP32_MFMA_PEAK_TFLOPS
             kname = ("conv_igemm_split_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp16 hi/lo x3 v_mfma_f32_32x32x16_f16, fp32 accumulate; "
                      "achieved counts ALGORITHMIC FLOPs, the matrix cores execute 3x that)") if split else \
-                "conv_igemm_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp32 v_mfma_f32_32x32x2_f32)"
+                "conv_split2_kernel<9,...,TERMS=0> (fused GroupNorm+SiLU+conv3x3, fp32 operands, v_mfma_f32_32x32x2_f32)"
             kname = kname.replace("conv_igemm_split_kernel", "conv_split2_kernel")
             if plain:
                 kname = "conv_split2_kernel<9,...,TERMS=1> (fused GroupNorm+SiLU+conv3x3, fp16 operands, one v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)"

@@ -88,7 +88,7 @@ struct S2Cfg {
   static constexpr int A1_F4 = 8 * HPS;                      // one activation tile image
   static constexpr int A_F4 = A_COPIES * A1_F4;  // 1x1: double-buffered (a new tile every step)
   static constexpr int B_F4 = 8 * BN;                            // LDS image of one tap's weight tile (hi and lo planes)
-  static constexpr int B_DMA_F4 = (TERMS == 3 ? 8 : 4) * BN;      // what is fetched: the single-product mode needs the hi plane only
+  static constexpr int B_DMA_F4 = (TERMS == 1 ? 4 : 8) * BN;      // what is fetched: the single-product mode needs the hi plane only
   static constexpr int B_PER = (B_DMA_F4 + NTHR - 1) / NTHR;      // LDS-DMA instructions per (issuing) wave per weight tile
   static constexpr int NG = TAPS / TPS;      // pipeline steps ("groups" of TPS taps) per 32-channel chunk
   static constexpr int G_PER = TPS * B_PER;  // LDS-DMA instructions per wave per group
@@ -113,7 +113,7 @@ struct S2Cfg {
   }
   static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
   static_assert(B_DMA_F4 % 64 == 0 && B_PER >= 1, "whole 1-KiB LDS-DMA instructions; a wave issues B_PER of them or none");
-  static_assert(TERMS == 3 || TERMS == 1, "3 = fp16 hi/lo split (fp32 accuracy), 1 = plain fp16 operands");
+  static_assert(TERMS == 3 || TERMS == 1 || TERMS == 0, "3 = fp16 hi/lo split (fp32 accuracy), 1 = plain fp16 operands, 0 = fp32 operands (exact fp32 MFMA)");
   static_assert(TERMS == 1 || B_DMA_F4 % NTHR == 0, "split mode: every wave owns the same number of distinct 1-KiB pieces");
   static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
   static_assert(R >= 2, "ring needs >= 2 slots");
@@ -333,6 +333,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           for (int k = 0; k < 8; ++k) v[k] = silu2(v[k]);
         }
         const bool ok = (avalid >> j) & 1u;  // conv zero padding applies after norm + activation
+        if constexpr (TERMS == 0) {
+          // exact-fp32 mode: the same LDS image with fp32 entries -- plane g holds channels 4g .. 4g+3 of the chunk (this thread's octet = planes
+          // 2 * l_o and 2 * l_o + 1), the same bytes per element as the hi + lo halves
+          const int hpl0 = lidx / C::OCT;
+          const int pixel0 = l_img * C::HPIP + (hpl0 / C::WT) * C::WTP + (hpl0 % C::WT);
+          Ad[(2 * l_o) * C::HPS + pixel0] = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          Ad[(2 * l_o + 1) * C::HPS + pixel0] = ok ? make_float4(v[4], v[5], v[6], v[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          return;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           _Float16 hh, ll;
@@ -476,6 +485,35 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #endif
     // One tap (or 32-channel slab pair) of MFMAs: LDS fragment reads + 3 MFMAs per 32x32x16 product
     auto mma_tap = [&](const float4* Ab, const float4* Bc, int tapoff, auto&& hook) {
+      if constexpr (TERMS == 0) {
+        // exact fp32: v_mfma_f32_32x32x2_f32 (one fp32 per lane and operand; lane half h supplies k = h).  Lane half h reads k-group 2j + h,
+        // so one b128 read per operand feeds four MFMAs; 16 MFMAs of 64 cycles per (tap, block): the matrix pipe has 5.3x the work of the
+        // split form per staged byte, under the same weight ring / staging / barrier schedule.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gi = 2 * j + h;
+          float4 af[MT], bf[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = Ab[gi * C::HPS + a_base[i] + tapoff];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) bf[c] = Bc[gi * C::BN + b_base[c]];
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[c].x, acc[i][c], 0, 0, 0);
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[c].y, acc[i][c], 0, 0, 0);
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[c].z, acc[i][c], 0, 0, 0);
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[c].w, acc[i][c], 0, 0, 0);
+            }
+          if (j == 0 || j == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            hook(j >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int seg = s2 * 2 + h;
@@ -996,11 +1034,16 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
   if (a.H % 4 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 4, 8, 4, 8, TERMS>(a, s);
   if (a.H % 4 == 0 && a.W % 4 == 0) return dispatch_s2_bn<TAPS, 4, 4, 4, 4, TERMS>(a, s);
   DRM_REQUIRE(a.w_img_stride_f4 == 0 && a.ksplit <= 1, "per-image weights / split-K need a map that is a whole number of tiles");
+  if constexpr (TERMS == 0) {
+    set_error("fp32 mode: ragged maps run on conv_igemm_kernel");
+    return DRM_ERR_INVALID;
+  } else {
   static const int fam[3][2] = {{8, 16}, {8, 8}, {4, 4}};
   switch (conv_tile_family(a.H, a.W, fam, 3)) {
     case 0: return dispatch_s2_ragged<TAPS, 8, 16, TERMS>(a, s);
     case 1: return dispatch_s2_ragged<TAPS, 8, 8, TERMS>(a, s);
     default: return dispatch_s2_ragged<TAPS, 4, 4, TERMS>(a, s);
+  }
   }
 }
 
@@ -1146,6 +1189,11 @@ int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s)
 }
 
 int launch_conv_split2(const ConvArgs& a, hipStream_t s) {
+  if (a.terms == 0) {  // exact fp32 operands on the same pipeline (DRM_PREC_FP32; maps that are a whole number of tiles)
+    DRM_REQUIRE(a.H % 4 == 0 && a.W % 4 == 0, "fp32 mode: maps that are not a whole number of 4x4 tiles run on conv_igemm_kernel");
+    if (a.taps == 9) return dispatch_s2_tile<9, 0>(a, s);
+    return dispatch_s2_tile<1, 0>(a, s);
+  }
   if (a.terms == 1) {  // plain fp16 operands, one MFMA per product (DRM_PREC_F16)
     if (a.taps == 9) return dispatch_s2_tile<9, 1>(a, s);
     return dispatch_s2_tile<1, 1>(a, s);

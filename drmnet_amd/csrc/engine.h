@@ -138,7 +138,7 @@ struct Ctx {
   int precision = PREC_FP32;
   bool dry() const { return ar->dry; }
   bool split() const { return precision == PREC_F16X3 || precision == PREC_F16; }
-  int terms() const { return precision == PREC_F16 ? 1 : 3; }
+  int terms() const { return precision == PREC_F16 ? 1 : (precision == PREC_FP32 ? 0 : 3); }  // ConvArgs::terms of the pipeline kernel
 };
 Act new_act(Ctx& c, int C, int H, int W);
 int ensure_moments(Ctx& c, Act& a);

@@ -288,9 +288,16 @@ int ensure_moments(Ctx& c, Act& a) {
 }
 
 // split-K factor the launch will use and the partial-slab workspace it then needs (allocated in sizing and real passes alike)
+// The pipeline kernel (conv_split2.hip: LDS-DMA weight ring, persistent tiles, fused output statistics) takes every conv whose channel counts
+// are whole 32-chunks: the two fp16 modes on any map, exact fp32 (TERMS = 0) on maps that are a whole number of 4x4 tiles.  The rest -- odd
+// channel counts of the per-module entry points, ragged maps in fp32 -- runs on conv_igemm_kernel (conv.hip).
+static bool on_pipeline(const Ctx& c, const ConvArgs& a) {
+  return (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0 && (c.split() || (a.H % 4 == 0 && a.W % 4 == 0));
+}
+
 float* plan_splitk(Ctx& c, ConvArgs& a) {
   a.ksplit = 1;
-  if (!(c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0)) return nullptr;
+  if (!on_pipeline(c, a)) return nullptr;
   a.ksplit = conv_split_ksplit(a);
   if (a.ksplit <= 1) return nullptr;
   a.split_stride = (size_t)a.N * a.H * a.W * a.Cout;
@@ -303,8 +310,8 @@ float* plan_splitk(Ctx& c, ConvArgs& a) {
 }
 
 int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_for, float* splitk_ws) {
-  if (c.split() && (a.C0 + a.C1) % 32 == 0 && a.C0 % 32 == 0) {
-    a.w_inv_scale = Wb + scale_off + 1;
+  if (on_pipeline(c, a)) {
+    a.w_inv_scale = c.split() ? Wb + scale_off + 1 : nullptr;  // (fp32 weights are packed unscaled)
     a.terms = c.terms();
     if (!splitk_ws) {
       a.ksplit = 1;

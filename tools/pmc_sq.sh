@@ -4,18 +4,21 @@
 # in their own passes with --kernel-trace only (no --stats / sys-trace), as the GPU pool requires.
 #   usage (on the GPU box): tools/pmc_sq.sh <tag>   -> gpurun_out/pmc_sq/<tag>_pmc_sq_conv.json   (copy it into profiles/)
 tag=${1:-r02}
+PREC=${2:-f16x3}   # f16x3 (conv_split2_kernel<9,...>) or fp32 (conv_igemm_kernel<9,...>)
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/pmc_sq"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
-  --kernel-trace -d "$OUT/p1" -- python3 "$ROOT/tools/layer_probe.py" f16x3 > "$OUT/p1.log" 2>&1
+  --kernel-trace -d "$OUT/p1" -- python3 "$ROOT/tools/layer_probe.py" $PREC > "$OUT/p1.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
-  --kernel-trace -d "$OUT/p2" -- python3 "$ROOT/tools/layer_probe.py" f16x3 > "$OUT/p2.log" 2>&1
+  --kernel-trace -d "$OUT/p2" -- python3 "$ROOT/tools/layer_probe.py" $PREC > "$OUT/p2.log" 2>&1
 cd "$ROOT"
-python3 - "$tag" <<'PY'
+python3 - "$tag" "$PREC" <<'PY'
 import collections, glob, hashlib, json, sqlite3, sys
 tag = sys.argv[1]
+prec = sys.argv[2]
+KERN = 'conv_igemm_kernel<9' if prec == 'fp32' else 'conv_split2_kernel<9'
 OUT = 'gpurun_out/pmc_sq'
 def rows(sub):
     dbs = sorted(glob.glob(f'{OUT}/{sub}/**/*_results.db', recursive=True))
@@ -32,7 +35,7 @@ for sub in ("p1", "p2"):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     meta = {}
     for disp, name, grid, cname, val, dur in rows(sub):
-        if 'conv_split2_kernel<9' not in name:
+        if KERN not in name:
             continue
         per[disp][cname] += val
         meta[disp] = (name.split('(')[0], grid, dur)
@@ -69,7 +72,7 @@ for sub in ("p1", "p2"):
         for k, v in avg.items():
             if k not in ("duration_ns",):
                 e.setdefault("raw", {})[k] = round(v, 1)
-json.dump(res, open(f'{OUT}/{tag}_pmc_sq_conv.json', 'w'), indent=1)
+json.dump(res, open(f'{OUT}/{tag}_pmc_sq_conv{"_fp32" if prec == "fp32" else ""}.json', 'w'), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
 rm -rf "$OUT/p1" "$OUT/p2"
