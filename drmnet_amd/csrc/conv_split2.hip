@@ -1132,12 +1132,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
     }
   }
   if (stat && gridDim.x > 1) {
-    __threadfence();  // this block's pairs are visible device-wide before its ticket is
+    // hand-off of this block's pairs (cdna_hip_programming.md Guideline 16): every storing wave drains its stores, the workgroup meets, ONE
+    // lane releases at agent scope and draws the ticket; the last arriver acquires once before the plain loads of its fold
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ticket + n, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_last = __hip_atomic_fetch_add(ticket + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+      if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
     __syncthreads();
     if (s_last) {
-      __threadfence();
       for (int c = threadIdx.x; c < Cout; c += 256) {
         double a = 0.0, c2 = 0.0;
         const double2* sp = stat_part + (size_t)n * gridDim.x * Cout + c;
@@ -1167,7 +1176,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
 // pixels per block of the reduction (a multiple of the 4 pixel lanes): about 128 blocks over the whole batch -- the loop is latency-bound,
 // the last block's fold grows with the blocks per image
 static int splitk_reduce_ppb(int N, int HW) {
-  int want = std::max(1, std::min(HW / 4, (128 + N - 1) / N));  // blocks per image
+  // (at most 32 blocks per image: the last arriver folds the blocks' pairs serially, eight loads in flight -- 128 blocks at batch 1 made that
+  //  fold 16 dependent round trips, most of the launch's 22 us)
+  int want = std::max(1, std::min(std::min(HW / 4, 32), (128 + N - 1) / N));  // blocks per image
   if (want <= 4) want = 1;  // a batch that fills the chip by itself: one block per image, nothing to fold
   return std::max(4, ((HW + want - 1) / want + 3) & ~3);
 }
