@@ -257,7 +257,7 @@ def cpu_baseline(args):
     return {"value": round(n / dt, 4), "unit": "U-Net denoise steps/sec", "cores": threads, "kind": "port",
             "sample": f"{n} DRMNet reverse steps (RefNet+IllNet, fp32) of 1 refmap 3x{H}x{W}, oracle/ on host CPU, {dt:.1f}s"}
 
-DOMINANT_VARIANT = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3>"
+DOMINANT_VARIANT = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3, false>"
 
 
 def kernel_source_hash() -> str:
