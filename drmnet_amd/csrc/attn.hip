@@ -395,6 +395,21 @@ static int launch_softmax_rows(float* S, long long rows, int T, hipStream_t s) {
   return DRM_OK;
 }
 
+// Images per attention pass: the [T, T] score matrices of a group live in the workspace between the S GEMM, the softmax and the PV GEMM.
+// The group bounds that workspace (1 GiB: 64 images at T = 2048 -- batch 256 used to need 4.3 GB per attention block) while keeping the
+// launches large.  Small groups that would keep the scores in the 256 MiB Infinity Cache were measured and lose: at batch 32, T = 2048 the
+// attention core takes 6.3 ms in one pass, 7.1 ms in 128 MiB groups, 8.8 ms in 64 MiB groups, 11.8 ms in 32 MiB groups (under-filled grids
+// and launch tails cost more than the HBM round trips of the scores).
+#ifndef DRM_ATTN_GROUP_MIB
+#define DRM_ATTN_GROUP_MIB 1024
+#endif
+int attention_group(int N, int T) {
+  const size_t per_image = (size_t)T * T * sizeof(float);
+  const size_t g = ((size_t)DRM_ATTN_GROUP_MIB << 20) / (per_image ? per_image : 1);
+  return (int)std::max<size_t>(1, std::min<size_t>(g, (size_t)N));
+}
+size_t attention_scores_floats(int N, int T) { return (size_t)attention_group(N, T) * T * T; }
+
 size_t attention_conv_workspace_floats(int N, int T, int C) {
   const size_t Z = (size_t)(C > T ? C : T);
   return 2 * (size_t)N * T * C + (size_t)N * (2 * C + T + Z) + 6 * (size_t)N + 64;
@@ -438,19 +453,24 @@ int launch_attention_conv(const float* qkv, const double2* qkv_mom, float* score
   hipLaunchKernelGGL(pack_attn_weight_kernel<false>, dim3(pb, N), dim3(256), 0, s, qkv + 2 * C, (long long)T * 3 * C, 3 * C, v_scale,
                      reinterpret_cast<float4*>(wv), C, T);
   DRM_HIP_CHECK(hipGetLastError());
-  ConvArgs a;  // S = alpha q k^T
-  a.src0 = qkv; a.C0 = C; a.ld0 = 3 * C; a.N = N; a.H = H; a.W = W;
-  a.gn_scale = q_tab; a.gn_shift = zero_tab; a.silu = 0;
-  a.w = wk; a.w_img_stride_f4 = (long long)T * C / 4; a.w_inv_img = k_inv; a.in_inv = qk_inv;
-  a.taps = 1; a.Cout = T; a.out = scores; a.terms = terms; a.prof_kind = PROF_KINDS;  // (inside the scope above)
-  DRM_TRY(launch_conv_split(a, s));
-  DRM_TRY(launch_softmax_rows(scores, (long long)N * T, T, s));
-  ConvArgs b;  // O = P v
-  b.src0 = scores; b.C0 = T; b.N = N; b.H = H; b.W = W;
-  b.gn_scale = p_tab; b.gn_shift = zero_tab; b.silu = 0;
-  b.w = wv; b.w_img_stride_f4 = (long long)T * C / 4; b.w_inv_img = v_inv; b.in_inv = pv_inv;
-  b.taps = 1; b.Cout = C; b.out = out; b.terms = terms; b.prof_kind = PROF_KINDS;
-  return launch_conv_split(b, s);
+  const int NB = attention_group(N, T);
+  for (int n0 = 0; n0 < N; n0 += NB) {  // one pass per image group (scores = the group's [nb, T, T] buffer)
+    const int nb = std::min(NB, N - n0);
+    ConvArgs a;  // S = alpha q k^T
+    a.src0 = qkv + (size_t)n0 * T * 3 * C; a.C0 = C; a.ld0 = 3 * C; a.N = nb; a.H = H; a.W = W;
+    a.gn_scale = q_tab + (size_t)n0 * C; a.gn_shift = zero_tab + (size_t)n0 * Z; a.silu = 0;
+    a.w = wk + (size_t)n0 * T * C; a.w_img_stride_f4 = (long long)T * C / 4; a.w_inv_img = k_inv + n0; a.in_inv = qk_inv + n0;
+    a.taps = 1; a.Cout = T; a.out = scores; a.terms = terms; a.prof_kind = PROF_KINDS;  // (inside the scope above)
+    DRM_TRY(launch_conv_split(a, s));
+    DRM_TRY(launch_softmax_rows(scores, (long long)nb * T, T, s));
+    ConvArgs b;  // O = P v
+    b.src0 = scores; b.C0 = T; b.N = nb; b.H = H; b.W = W;
+    b.gn_scale = p_tab + (size_t)n0 * T; b.gn_shift = zero_tab + (size_t)n0 * Z; b.silu = 0;
+    b.w = wv + (size_t)n0 * T * C; b.w_img_stride_f4 = (long long)T * C / 4; b.w_inv_img = v_inv + n0; b.in_inv = pv_inv + n0;
+    b.taps = 1; b.Cout = C; b.out = out + (size_t)n0 * T * C; b.terms = terms; b.prof_kind = PROF_KINDS;
+    DRM_TRY(launch_conv_split(b, s));
+  }
+  return DRM_OK;
 }
 
 int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms) {
@@ -461,27 +481,31 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
   prof_tag(N, T, 1, C, C);
   ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C + 4.0 * T * T), s);
   split = split && (C % 32 == 0) && (T % 32 == 0);
-  if (split && terms == 1)
-    hipLaunchKernelGGL((bgemm64s_kernel<true, 1>), dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
-                       (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha, 1.0f);
-  else if (split)
-    hipLaunchKernelGGL((bgemm64s_kernel<true, 3>), dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
-                       (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha, 1.0f);
-  else
-    hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, N), dim3(256), 0, s, qkv, qkv + C, scores, T, T, C, 3 * C, 3 * C, T,
-                       (long long)T * 3 * C, (long long)T * 3 * C, (long long)T * T, alpha);
-  DRM_HIP_CHECK(hipGetLastError());
-  DRM_TRY(launch_softmax_rows(scores, (long long)N * T, T, s));
-  if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
-    hipLaunchKernelGGL((bgemm64s_kernel<false, 1>), dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
-                       (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
-  else if (split)
-    hipLaunchKernelGGL((bgemm64s_kernel<false, 3>), dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
-                       (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
-  else
-    hipLaunchKernelGGL(bgemm64_kernel<false>, dim3((C + 63) / 64, tb, N), dim3(256), 0, s, scores, qkv + 2 * C, out, T, C, T, T, 3 * C, C,
-                       (long long)T * T, (long long)T * 3 * C, (long long)T * C, 1.0f);
-  DRM_HIP_CHECK(hipGetLastError());
+  const int NB = attention_group(N, T);
+  const long long sq = (long long)T * 3 * C;  // image stride of qkv
+  for (int n0 = 0; n0 < N; n0 += NB) {
+    const int nb = std::min(NB, N - n0);
+    const float* qg = qkv + (size_t)n0 * sq;
+    float* og = out + (size_t)n0 * T * C;
+    if (split && terms == 1)
+      hipLaunchKernelGGL((bgemm64s_kernel<true, 1>), dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha, 1.0f);
+    else if (split)
+      hipLaunchKernelGGL((bgemm64s_kernel<true, 3>), dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha, 1.0f);
+    else
+      hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha);
+    DRM_HIP_CHECK(hipGetLastError());
+    DRM_TRY(launch_softmax_rows(scores, (long long)nb * T, T, s));
+    if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
+      hipLaunchKernelGGL((bgemm64s_kernel<false, 1>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
+                         (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
+    else if (split)
+      hipLaunchKernelGGL((bgemm64s_kernel<false, 3>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
+                         (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
+    else
+      hipLaunchKernelGGL(bgemm64_kernel<false>, dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
+                         (long long)T * T, sq, (long long)T * C, 1.0f);
+    DRM_HIP_CHECK(hipGetLastError());
+  }
   return DRM_OK;
 }
 

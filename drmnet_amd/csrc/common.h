@@ -135,6 +135,9 @@ int launch_erode_mask(const unsigned char* mask, int H, int W, int k, unsigned c
 int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms = 0);
 // split-precision attention core on the fused 1x1 conv pipeline (per-image weights = k, v^T); T = H*W must be a multiple of 256
 bool attention_conv_applicable(int T, int C, int H, int W, int terms);
+// images per attention pass and the score workspace that takes ([group, T, T] floats: independent of the batch beyond one group)
+int attention_group(int N, int T);
+size_t attention_scores_floats(int N, int T);
 size_t attention_conv_workspace_floats(int N, int T, int C);
 struct ConvArgs;
 int launch_attention_conv(const float* qkv, const double2* qkv_mom, float* scores, float* out, float* ws, int N, int H, int W, int C, int terms,

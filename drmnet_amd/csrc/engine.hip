@@ -449,7 +449,7 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   DRM_TRY(gn_params(c, x, nullptr, Wb + l.n_w, Wb + l.n_b, sc, sh));
   Act qkv_act = new_act(c, 3 * C, H, W);  // its per-channel sums (fused into the qkv conv's epilogue) bound |v| >= |attention output|
   float* qkv = qkv_act.p;
-  float* scores = c.ar->alloc<float>((size_t)c.N * T * T);
+  float* scores = c.ar->alloc<float>(attention_scores_floats(c.N, T));  // one image group at a time (attn.hip attention_group)
   float* att = c.ar->alloc<float>((size_t)c.N * T * C);
   const bool on_conv = c.split() && attention_conv_applicable(T, C, H, W, c.terms());  // the T >= 512 levels: both GEMMs on the conv pipeline
   float* aws = on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C)) : nullptr;
