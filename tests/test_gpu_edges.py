@@ -85,3 +85,39 @@ def test_c_abi_rejects_bad_arguments_with_a_message(dev):
                             _lib.stream_ptr(dev))
     assert rc != 0 and len(L.drm_last_error()) > 0  # N = 0 is the caller's business (the host mirror returns early)
     torch.cuda.synchronize()
+
+
+def test_two_handles_on_two_streams_from_two_threads(dev):
+    """include/drmnet_hip.h: entry points take the stream to launch on and are re-entrant across distinct handles and streams (error strings
+    are thread-local, per-kernel attributes are set idempotently, a handle owns its weights and the caller its workspace).  Two networks
+    driven from two host threads on two non-default streams, interleaved, must give what each gives alone."""
+    import threading
+
+    nets = [_net(UNetModel, dev).set_precision("f16x3"), _net(UNetModel, dev, model_channels=64).set_precision("fp32")]
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn((n, 6, 16, 32), generator=g).to(dev) for n in (3, 5)]
+    ts = [torch.randint(0, 1000, (n,), generator=g).to(dev) for n in (3, 5)]
+    refs = [m(x, timesteps=t).clone() for m, x, t in zip(nets, xs, ts)]
+    torch.cuda.synchronize()
+    outs, errs = [[], []], []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    outs[k].append(nets[k](xs[k], timesteps=ts[k]))
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs, errs
+    for k in (0, 1):
+        assert len(outs[k]) == 25
+        for o in outs[k]:
+            assert torch.allclose(o, refs[k], rtol=0, atol=2e-6 * float(refs[k].abs().max()))
