@@ -923,7 +923,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
   long long grid = (long long)di->cus * per_cu;
   const int ngt = ((a.C0 + a.C1) / C::KC) * C::NG;  // weight groups per tile
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  DRM_REQUIRE(ks == 1 || (TAPS == 9 && !a.out_nchw && !a.stat_out && a.split_stride > 0 && ((a.C0 + a.C1) / C::KC) / ks >= 1), "split-K launch contract");
+  DRM_REQUIRE(ks == 1 || (!a.out_nchw && !a.stat_out && a.split_stride > 0 && a.w_img_stride_f4 == 0 && ((a.C0 + a.C1) / C::KC) / ks >= 1), "split-K launch contract");
   if (tiles < grid || ngt < R - 1 || (TAPS == 1 && ngt < 2) || ks > 1) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
   {
     const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
@@ -1051,7 +1051,9 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
 // their grid leaves most of the 256 CUs idle and the reduction is long; the caller zero-fills nothing (the launcher does) but
 // must not ask for fused output statistics (partial sums have no statistics) -- engine.hip:run_conv checks this first.
 int conv_split_ksplit(const ConvArgs& a) {
-  if (a.taps != 9 || a.out_nchw || !s2_exact(a)) return 1;
+  if (a.out_nchw || !s2_exact(a) || a.w_img_stride_f4 != 0) return 1;
+  // (1x1 convs too [r3]: on the deep, small maps a K = 768 .. 1536 reduction is 24 .. 48 serial one-chunk steps of a handful of workgroups --
+  //  30 us at batch 1 whatever the map; split, they are ~5 chunks each plus the small-map reduction)
   const long long rows = (long long)a.N * a.H * a.W;
   auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
   if (a.Cout % 128 == 0 && wgs(256, 128) >= S2_MIN_WIDE_TILES) return 1;
@@ -1173,6 +1175,65 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
   }
 }
 
+// Small maps (H * W <= 256: the deep levels, every level at batch 1): the same fixed-order reduction with the whole image in ONE block per 16
+// channel quads -- 16 quads x 16 pixel lanes, so a lane walks at most 16 pixels with its slab loads in flight together, the lanes of a channel
+// fold in LDS in lane order and the block's sums ARE the statistics: no partial table, no ticket, no fence.  (The general kernel below spent most
+// of its 17-22 us per launch at batch 1 in serial passes over the channel quads and in the last-arriver hand-off.)
+__global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float4* __restrict__ partial, size_t slab_f4, int ks, const float* __restrict__ bias,
+                                                                  const float* __restrict__ emb, int emb_stride, const float* res /* may alias out */,
+                                                                  float4* out, double2* __restrict__ stat, int HW, int Cout) {
+  __shared__ float red[256][8];
+  const int n = blockIdx.y, q4 = Cout >> 2;
+  const int ql = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int q = blockIdx.x * 16 + ql;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < q4) {
+    if (bias) b = reinterpret_cast<const float4*>(bias)[q];
+    if (emb) {
+      const float4 e = *reinterpret_cast<const float4*>(emb + (size_t)n * emb_stride + 4 * q);
+      b.x += e.x; b.y += e.y; b.z += e.z; b.w += e.w;
+    }
+  }
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int p = pl; p < HW && q < q4; p += 16) {
+    const size_t idx = ((size_t)n * HW + p) * q4 + q;
+    float4 acc = partial[idx];
+    for (int k = 1; k < ks; ++k) {
+      const float4 t = partial[idx + (size_t)k * slab_f4];
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    float4 v = make_float4(acc.x + b.x, acc.y + b.y, acc.z + b.z, acc.w + b.w);
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[idx];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    out[idx] = v;
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
+  }
+  if (stat) {  // (uniform per launch)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[threadIdx.x][k] = s[k];
+      red[threadIdx.x][4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (pl == 0 && q < q4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double a = 0.0, c2 = 0.0;
+        for (int j = 0; j < 16; ++j) {  // fixed order
+          a += (double)red[j * 16 + ql][k];
+          c2 += (double)red[j * 16 + ql][4 + k];
+        }
+        double2* d = stat + (size_t)n * Cout + 4 * q + k;
+        *d = make_double2(d->x + a, d->y + c2);
+      }
+    }
+  }
+}
+
 // pixels per block of the reduction (a multiple of the 4 pixel lanes): about 128 blocks over the whole batch -- the loop is latency-bound,
 // the last block's fold grows with the blocks per image
 static int splitk_reduce_ppb(int N, int HW) {
@@ -1190,6 +1251,12 @@ int splitk_reduce_blocks(int N, int H, int W) {
 int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s) {
   DRM_REQUIRE(a.ksplit > 1 && a.split_stride % 4 == 0 && a.Cout % 4 == 0, "split-K reduction arguments");
   const int HW = a.H * a.W;
+  if (HW <= 256) {
+    hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((a.Cout / 4 + 15) / 16, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),
+                       a.split_stride / 4, a.ksplit, a.bias, a.emb, a.emb_stride, a.res, reinterpret_cast<float4*>(a.out), a.stat_out, HW, a.Cout);
+    DRM_HIP_CHECK(hipGetLastError());
+    return DRM_OK;
+  }
   const int ppb = splitk_reduce_ppb(a.N, HW);
   DRM_REQUIRE(!a.stat_out || (a.stat_part && a.stat_ticket), "split-K reduction with statistics needs its partial table and ticket counters");
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((HW + ppb - 1) / ppb, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),

@@ -420,14 +420,18 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
   ConvArgs b;  // out_layers conv: GroupNorm(h1) -> SiLU -> 3x3 + residual
   b.src0 = h1.p; b.C0 = r.cout; b.N = c.N; b.H = H; b.W = W; b.taps = 9; b.Cout = r.cout;
   float* ws2 = plan_splitk(c, b);
+  float* wsk = nullptr;
+  if (r.has_skip) {
+    k.C0 = C0; k.C1 = C1; k.N = c.N; k.H = H; k.W = W; k.taps = 1; k.Cout = r.cout;
+    wsk = plan_splitk(c, k);
+  }
   if (!c.dry()) {
     const float* res = x0.p;
     if (r.has_skip) {
-      k.src0 = x0.p; k.src1 = x1 ? x1->p : nullptr; k.C0 = C0; k.C1 = C1; k.up0 = x0.up;
-      k.N = c.N; k.H = H; k.W = W;
-      k.w = Wb + r.sk_w; k.bias = Wb + r.sk_b; k.taps = 1; k.Cout = r.cout;
+      k.src0 = x0.p; k.src1 = x1 ? x1->p : nullptr; k.up0 = x0.up;
+      k.w = Wb + r.sk_w; k.bias = Wb + r.sk_b;
       k.out = out.p;
-      DRM_TRY(run_conv(c, k, Wb, r.sk_s));
+      DRM_TRY(run_conv(c, k, Wb, r.sk_s, nullptr, wsk));
       res = out.p;
     }
     b.gn_scale = sc2; b.gn_shift = sh2; b.silu = 1;
@@ -454,12 +458,16 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   const bool on_conv = c.split() && attention_conv_applicable(T, C, H, W, c.terms());  // the T >= 512 levels: both GEMMs on the conv pipeline
   float* aws = on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C)) : nullptr;
   ConvArgs p;  // proj_out: 1x1 conv on the raw attention output, a convex combination of v rows: max |att| <= max |v|
+  ConvArgs a;  // qkv: GroupNorm(x) -> 1x1
+  a.C0 = C; a.N = c.N; a.H = H; a.W = W; a.taps = 1; a.Cout = 3 * C;
+  float* wsq = plan_splitk(c, a);
+  p.C0 = C; p.N = c.N; p.H = H; p.W = W; p.taps = 1; p.Cout = C;
+  float* wsp = plan_splitk(c, p);
   if (!c.dry()) {
-    ConvArgs a;
-    a.src0 = x.p; a.C0 = C; a.N = c.N; a.H = H; a.W = W;
+    a.src0 = x.p;
     a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
-    a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.taps = 1; a.Cout = 3 * C; a.out = qkv;
-    DRM_TRY(run_conv(c, a, Wb, l.qkv_s, &qkv_act));
+    a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.out = qkv;
+    DRM_TRY(run_conv(c, a, Wb, l.qkv_s, &qkv_act, wsq));
     if (on_conv) DRM_TRY(launch_attention_conv(qkv, qkv_act.mom, scores, att, aws, c.N, H, W, C, c.terms(), c.s, &p));
     else DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split() ? c.terms() : 0));
   } else {
@@ -468,9 +476,9 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   }
   if (!on_conv) DRM_TRY(raw_input_guard(c, p, &qkv_act, 2 * C, 3 * C, nullptr, nullptr, C));  // (the conv-pipeline core hands p its guard tables)
   if (!c.dry()) {
-    p.src0 = att; p.C0 = C; p.N = c.N; p.H = H; p.W = W;
-    p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.taps = 1; p.Cout = C; p.res = x.p; p.out = out.p;
-    DRM_TRY(run_conv(c, p, Wb, l.proj_s, &out));
+    p.src0 = att;
+    p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.res = x.p; p.out = out.p;
+    DRM_TRY(run_conv(c, p, Wb, l.proj_s, &out, wsp));
   }
   c.ar->release(mark);
   return DRM_OK;
