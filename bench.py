@@ -444,6 +444,45 @@ def secondary_pass(args, model, dev):
     return out
 
 
+def full_chain_all_ranks(args, model, dev, dist):
+    """Metric part 2 at N GPUs ("full-chain samples/sec @1/8 GPU"): every rank runs the whole chain (object images -> refmaps -> ObsNet DDIM-50
+    -> DRMNet loop, early exit off so the work is countable) on its own 32 synthetic objects -- batches shard by object, no collective on the
+    path -- bracketed by barriers; time = MAX over ranks, work = SUM (rank_aggregate).  Runs after the headline measurement, on N > 1 only
+    (at N = 1 the `secondary.full_chain` object carries it with per-stage times).  A rank that fails still meets the others at every barrier."""
+    from drmnet_amd.config import instantiate_from_config, load_config
+    from drmnet_amd.estimate import estimate_batch
+
+    B, err, run = 32, None, None
+    try:
+        obs = build_models("obsnet", dev, "f16x3")
+        obs.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["data"]["params"]["predict"])
+        model.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/drmnet/eval_drmnet.yaml"))["data"]["params"]["predict"])
+        imgs, normals, masks = chain_inputs(B, dev)
+        run = lambda seed: estimate_batch(model, obs, imgs, normals, masks, early_exit=False, seed=seed)
+        run(7)  # warm-up
+        torch.cuda.synchronize(dev)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    try:
+        if err is None:
+            run(8)
+            torch.cuda.synchronize(dev)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if dist is not None:
+        dist.barrier()
+    dt, total = rank_aggregate(time.perf_counter() - t0, float(B) if err is None else 0.0, dist, dev)
+    bad, _ = rank_aggregate(0.0, 0.0 if err is None else 1.0, dist, dev) if dist is not None else (0.0, 0.0 if err is None else 1.0)
+    out = {"value": round(total / dt, 3) if dt > 0 else None, "unit": "object images/sec (all ranks)", "objects_per_gpu": B, "s_per_batch": round(dt, 3),
+           "ddim_steps": 50, "max_timesteps": int(model.max_timesteps), "early_exit": False}
+    if err is not None or _ > 0:
+        out["error"] = err or f"{int(_)} other rank(s) failed"
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -460,23 +499,21 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    json_fd = None  # where the one JSON line goes when fd 1 had to be pointed away from stdout
     if world > 1 or os.environ.get("DRM_BENCH_DIST") == "1":  # (DRM_BENCH_DIST=1: exercise the RCCL path with a single rank)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL prints a version banner on STDOUT when its communicator comes up; stdout carries the one JSON line only, so the
         # communicator is created (init + a first collective) with fd 1 pointed at stderr
+        # -- and stays there for the whole run (the banner was also seen AFTER the JSON line, printed from a later collective / at teardown):
+        # the JSON line is written to the saved descriptor of the real stdout
         sys.stdout.flush()
-        saved_fd = os.dup(1)
+        json_fd = os.dup(1)
         os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
 
     from drmnet_amd import _lib
 
@@ -563,6 +600,9 @@ def main():
             # launch of the dominant variant -- and only when that profile was taken on the kernel source this build was made from.
             roofline.update(imported_traffic(split and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256)))
 
+    chain_all = None
+    if (world > 1 or dist is not None) and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_secondary:
+        chain_all = full_chain_all_ranks(args, model, dev, dist)  # (DRM_BENCH_DIST=1 exercises it with a single rank)
     if rank == 0:
         value = total_units / dt
         out = {
@@ -587,6 +627,8 @@ def main():
             "kernel_breakdown_note": "conv3x3 row and the roofline object: HIP events inside the timed region; other rows: a second, untimed pass of the same steps with every kernel family instrumented",
         }
         out["state_finite"] = state_finite
+        if chain_all is not None:
+            out["full_chain_all_gpus"] = chain_all
         if args.workload == "drmnet_step" and not args.no_parity_check:
             out["parity_check"] = parity_check(model, dev, args.precision)
         if world == 1 and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_strict_fp32:
@@ -603,7 +645,10 @@ def main():
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and args.workload == "drmnet_step":
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        if json_fd is None:
+            print(json.dumps(out), flush=True)
+        else:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -140,3 +140,29 @@ def test_brdf_schedule_host_math(drmnet):
         zk, zK = drmnet.get_brdf_out(z_out, reversed_k=i)
         assert torch.equal(zk, torch.from_numpy(g[f"zk_{i}"]))
         assert torch.equal(drmnet.check_convergence(zk), torch.from_numpy(g[f"conv_{i}"]))
+
+
+def test_constructors_accept_training_keys_and_reject_unknown_ones():
+    """The reference's YAMLs carry training-only keys (losses, monitors, caches: models/drmnet.py:79-240, ddpm.py:60-135): they are accepted and
+    ignored; a key neither the inference path nor that list knows is an error, and unsupported VALUES of known keys raise loudly."""
+    from drmnet_amd.drmnet import DRMNet
+    from drmnet_amd.obsnet import ObsNetDiffusion
+
+    dparams = dict(model_cfg("configs/drmnet/eval_drmnet.yaml")["model"]["params"])
+    tiny_u = {"target": dparams["illnet_config"]["target"], "params": dict(image_size=16, in_channels=6, out_channels=3, model_channels=32,
+              attention_resolutions=[2], num_res_blocks=1, channel_mult=[1, 2], num_heads=1, resblock_updown=False, conv_resample=False)}
+    tiny_e = {"target": dparams["refnet_config"]["target"], "params": dict(tiny_u["params"], out_channels=6, pool="adaptive")}
+    base = dict(dparams, illnet_config=tiny_u, refnet_config=tiny_e, use_ema=False)
+    m = DRMNet(**dict(base, loss_type="l1", monitor="val/loss", l_refmap_weight=2.0, cache_refmap=True, sigma=0.3))
+    assert not hasattr(m, "l_refmap_weight") and not hasattr(m, "loss_type")
+    with pytest.raises(TypeError):
+        DRMNet(**dict(base, definitely_not_a_reference_key=1))
+    with pytest.raises(NotImplementedError):
+        DRMNet(**dict(base, scale_by_std=True))
+    oparams = dict(model_cfg("configs/obsnet/eval_obsnet.yaml")["model"]["params"], unet_config=tiny_u, use_ema=False, image_size=16)
+    o = ObsNetDiffusion(**dict(oparams, original_elbo_weight=0.5, l_simple_weight=2.0, use_positional_encodings=True))
+    assert o.ddim_steps == 50 and o.clip_denoised is False and not hasattr(o, "l_simple_weight")
+    with pytest.raises(TypeError):
+        ObsNetDiffusion(**dict(oparams, not_a_key=True))
+    with pytest.raises(NotImplementedError):
+        ObsNetDiffusion(**dict(oparams, parameterization="x0"))
