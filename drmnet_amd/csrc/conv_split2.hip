@@ -316,32 +316,33 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     tie_regs(sc[0], sc[1]);
     tie_regs(sh[0], sh[1]);
   };
-  auto store_A_slot = [&](float4* Ad, int j) {
-    {
-      const int lidx = l_tid + C::TPI * j;
-      if (lidx < C::HPI * C::OCT) {
+  // Staging of a loaded slot in two halves: transform (GroupNorm affine + SiLU + hi/lo split, VALU only, IN PLACE in the slot's eight
+  // registers: areg[j][0] <- eight hi halfs or the first four fp32 values, areg[j][1] <- the lo halfs or the other four) and write (two
+  // ds_write_b128).  At a chunk end of the 3x3 loop the transform runs BEFORE the barrier that frees the activation tile: the wave of a SIMD
+  // that finishes its MFMAs first transforms under its partner's MFMAs instead of idling at that barrier, and the later one then has the
+  // SIMD's VALU to itself (after the barrier both used to share it) -- only the LDS writes are left between the two chunk-end barriers.
+  auto transform_A_slot = [&](int j) {
+    const int lidx = l_tid + C::TPI * j;
+    if (lidx < C::HPI * C::OCT) {
+      float v[8] = {areg[j][0].x, areg[j][0].y, areg[j][0].z, areg[j][0].w, areg[j][1].x, areg[j][1].y, areg[j][1].z, areg[j][1].w};
+      if (has_gn) {
+        const float s8[8] = {sc[0].x, sc[0].y, sc[0].z, sc[0].w, sc[1].x, sc[1].y, sc[1].z, sc[1].w};
+        const float b8[8] = {sh[0].x, sh[0].y, sh[0].z, sh[0].w, sh[1].x, sh[1].y, sh[1].z, sh[1].w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] * s8[k] + b8[k];
+      }
+      if (a.silu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = silu2(v[k]);
+      }
+      const bool ok = (avalid >> j) & 1u;  // conv zero padding applies after norm + activation
+      if constexpr (TERMS == 0) {
+        // exact-fp32 mode: the same LDS image with fp32 entries -- plane g holds channels 4g .. 4g+3 of the chunk (this thread's octet = planes
+        // 2 * l_o and 2 * l_o + 1), the same bytes per element as the hi + lo halves
+        areg[j][0] = ok ? f32x4{v[0], v[1], v[2], v[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+        areg[j][1] = ok ? f32x4{v[4], v[5], v[6], v[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
         F4H8b hi, lo;
-        float v[8] = {areg[j][0].x, areg[j][0].y, areg[j][0].z, areg[j][0].w, areg[j][1].x, areg[j][1].y, areg[j][1].z, areg[j][1].w};
-        if (has_gn) {
-          const float s8[8] = {sc[0].x, sc[0].y, sc[0].z, sc[0].w, sc[1].x, sc[1].y, sc[1].z, sc[1].w};
-          const float b8[8] = {sh[0].x, sh[0].y, sh[0].z, sh[0].w, sh[1].x, sh[1].y, sh[1].z, sh[1].w};
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = v[k] * s8[k] + b8[k];
-        }
-        if (a.silu) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = silu2(v[k]);
-        }
-        const bool ok = (avalid >> j) & 1u;  // conv zero padding applies after norm + activation
-        if constexpr (TERMS == 0) {
-          // exact-fp32 mode: the same LDS image with fp32 entries -- plane g holds channels 4g .. 4g+3 of the chunk (this thread's octet = planes
-          // 2 * l_o and 2 * l_o + 1), the same bytes per element as the hi + lo halves
-          const int hpl0 = lidx / C::OCT;
-          const int pixel0 = l_img * C::HPIP + (hpl0 / C::WT) * C::WTP + (hpl0 % C::WT);
-          Ad[(2 * l_o) * C::HPS + pixel0] = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-          Ad[(2 * l_o + 1) * C::HPS + pixel0] = ok ? make_float4(v[4], v[5], v[6], v[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
-          return;
-        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           _Float16 hh, ll;
@@ -349,17 +350,39 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           hi.h8[k] = hh;
           lo.h8[k] = ll;
         }
-        const int hpl = lidx / C::OCT;
-        const int pixel = l_img * C::HPIP + (hpl / C::WT) * C::WTP + (hpl % C::WT);
-        Ad[l_o * C::HPS + pixel] = hi.f4;
-        if (TERMS == 3) Ad[(4 + l_o) * C::HPS + pixel] = lo.f4;
+        areg[j][0] = f32x4{hi.f4.x, hi.f4.y, hi.f4.z, hi.f4.w};
+        areg[j][1] = f32x4{lo.f4.x, lo.f4.y, lo.f4.z, lo.f4.w};
       }
     }
   };
-  auto store_A = [&](float4* Ad) {
+  auto write_A_slot = [&](float4* Ad, int j) {
+    const int lidx = l_tid + C::TPI * j;
+    if (lidx < C::HPI * C::OCT) {
+      const int hpl = lidx / C::OCT;
+      const int pixel = l_img * C::HPIP + (hpl / C::WT) * C::WTP + (hpl % C::WT);
+      const float4 w0 = make_float4(areg[j][0].x, areg[j][0].y, areg[j][0].z, areg[j][0].w);
+      const float4 w1 = make_float4(areg[j][1].x, areg[j][1].y, areg[j][1].z, areg[j][1].w);
+      if constexpr (TERMS == 0) {
+        Ad[(2 * l_o) * C::HPS + pixel] = w0;
+        Ad[(2 * l_o + 1) * C::HPS + pixel] = w1;
+      } else {
+        Ad[l_o * C::HPS + pixel] = w0;
+        if (TERMS == 3) Ad[(4 + l_o) * C::HPS + pixel] = w1;
+      }
+    }
+  };
+  auto transform_A = [&]() {
     tie_A();
 #pragma unroll
-    for (int j = 0; j < C::A_SLOTS; ++j) store_A_slot(Ad, j);
+    for (int j = 0; j < C::A_SLOTS; ++j) transform_A_slot(j);
+  };
+  auto write_A = [&](float4* Ad) {
+#pragma unroll
+    for (int j = 0; j < C::A_SLOTS; ++j) write_A_slot(Ad, j);
+  };
+  auto store_A = [&](float4* Ad) {
+    transform_A();
+    write_A(Ad);
   };
   // ---- weight groups: LDS-DMA, G_PER x 1 KiB per wave per group; LDS image == packed global layout.
   //      `gseq` counts groups since kernel start (ring slot = gseq % R); (g_in_tile, co0) say which weights.
@@ -650,11 +673,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
         if (last_g) {
           if (a_next) {
-            __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
-            S2_STAMP(4);  // barrier 1 of the chunk end passed
             wait_vmcnt<C::G_PER * (C::NG - 1 - A_G)>();  // the request of group A_G; younger: the weight groups issued after it
             S2_STAMP(5);  // activation loads landed
-            store_A(As);
+            transform_A();  // (registers only: ahead of the barrier, under the partner wave's MFMAs)
+            __builtin_amdgcn_sched_barrier(0);  // (the compiler may not sink register-only work below the barrier)
+            __builtin_amdgcn_s_barrier();  // every wave finished reading the old activation tile
+            S2_STAMP(4);  // barrier 1 of the chunk end passed
+            write_A(As);
             S2_STAMP(6);  // staged (GroupNorm affine + SiLU + split + LDS writes)
             wait_vmcnt<BASE>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
