@@ -415,6 +415,21 @@ def secondary_pass(args, model, dev):
             chains[f"{prec}_{'graph' if graph else 'eager'}"] = {"value": round(256 * 50 / dt, 1), "unit": unit, "s_per_chain": round(dt, 3),
                                                                   "finite": bool(torch.isfinite(res["x"]).all().item())}
     ops.set_graph_replay(False)
+    # the literal wording of configs[1] ("reverse DDPM 1000-step, batch 32"): the only 1000-step schedule of the reference is ObsNet's ancestral
+    # sampler: 100 of its 1000 steps through the device loop (the per-step cost does not depend on t), fp32-accurate mode
+    try:
+        obs.set_precision("f16x3")
+        x32, xT32 = x[:32].contiguous(), xT[:32].contiguous()
+        res = {}
+
+        def ddpm():
+            res["x"] = obs.p_sample_loop(x32, tuple(x32.shape), x_T=xT32, verbose=False, start_T=100, seed=3)
+
+        dt = timed(ddpm, 1, warm=1)
+        out["obsnet_ancestral_ddpm_b32_3x128x256"] = {"value": round(32 * 100 / dt, 1), "unit": unit, "s_per_100_steps": round(dt, 3), "steps_timed": 100,
+                                                     "of_schedule": 1000, "finite": bool(torch.isfinite(res["x"]).all().item()), "precision": "f16x3"}
+    except Exception as e:  # noqa: BLE001
+        out["obsnet_ancestral_ddpm_b32_3x128x256"] = {"error": f"{type(e).__name__}: {e}"}
     chains["note"] = ("f16x3 = fp32-accurate split mode (1e-4 contract); f16 = fp16 operands, fp32 accumulate: the reduced-precision mode standing in for "
                       "configs[2]'s bf16 (more mantissa, guarded range; 5e-3 tolerance, tests/test_gpu_configs.py)")
     out["obsnet_ddim50_chain_b256_3x128x256"] = chains
@@ -438,6 +453,27 @@ def secondary_pass(args, model, dev):
         steps = int(K.sum().item()) if ee else B * model.max_timesteps
         fc[tag] = {"value": round(B / dt, 3), "unit": "object images/sec", "s_per_batch": round(dt, 3), "stage_ms": {k: round(v, 1) for k, v in tm.items()},
                    "drmnet_sample_steps": steps, "K_min_max": [int(K.min().item()), int(K.max().item())]}
+    # ---- the reference's own use: scripts/estimate.py on ONE object image (data/sample: 256x256 EXR + normals + mask), full-width networks
+    try:
+        import numpy as np
+        from drmnet_amd import file_io
+        from drmnet_amd.estimate import estimate
+
+        d = os.path.join(ROOT, "tests", "golden", "sample")
+        img = file_io.load_exr(os.path.join(d, "image.exr"), as_torch=True).to(dev)
+        nrm = torch.from_numpy(np.load(os.path.join(d, "normal.npy"))).to(dev)
+        msk = torch.logical_and(file_io.load_png(os.path.join(d, "mask.png"), as_torch=True).to(dev) > 0, torch.linalg.norm(nrm, dim=-1) > 0.5)
+        estimate(model, obs, img, nrm, msk)  # warm-up
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        estimate(model, obs, img, nrm, msk)
+        torch.cuda.synchronize(dev)
+        dt1 = time.perf_counter() - t0
+        out["estimate_single_image"] = {"value": round(dt1, 3), "unit": "s per object image (wall, host included)", "drmnet_steps": int(model.last_steps),
+                                        "ddim_steps": obs.ddim_steps, "note": "estimate() on tests/golden/sample (the reference's data/sample), 128x128 refmap, batch 1, "
+                                        "natural early exit of the synthetic RefNet"}
+    except (OSError, KeyError) as e:  # sample files not shipped with this copy
+        out["estimate_single_image"] = {"error": str(e)}
     fc["note"] = ("value = whole-call wall time (host included). Random-weight networks do not converge the way trained ones do: the natural-exit row shows the "
                   "early-exit machinery at whatever K the synthetic RefNet produces; the early-exit-off row is the countable one (150 steps per object)")
     out["full_chain"] = fc
