@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim", "obsnet_ddim_chain", "estimate_chain"])
-    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "f16"],
+    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "f16", "f16mx"],
                     help="conv arithmetic: f16x3 (default) = every fp32 operand split into fp16 hi+lo, 3 MFMAs per product, fp32 "
                          "accumulate: passes the SAME parity tolerances as fp32 (tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -609,7 +609,8 @@ def main():
                                 "algorithmic_GBps": round(by[k] / ms[k] / 1e6, 1) if ms[k] > 0 else None} for k in range(K) if n[k] > 0}
         if n[0] > 0:
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
-            split = args.precision == "f16x3"
+            split = args.precision in ("f16x3", "f16mx")
+            mx = args.precision == "f16mx"
             plain = args.precision == "f16"  # reduced precision (BASELINE configs[2]); never the default
             peak = F16_MFMA_PEAK_TFLOPS if (split or plain) else FP32_MFMA_PEAK_TFLOPS
             kname = ("conv_igemm_split_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp16 hi/lo x3 v_mfma_f32_32x32x16_f16, fp32 accumulate; "
@@ -623,7 +624,12 @@ def main():
                         "traffic": None, "launches": int(n[0]), "avg_launch_ms": round(ms[0] / n[0], 4),
                         "flops_per_launch": round(fl[0] / n[0], 1), "algorithmic_bytes_per_launch": round(by[0] / n[0], 1),
                         "share_of_step_time": round(ms[0] * 1e-3 / dt, 3)}
-            if split:  # the matrix cores execute three f16 MFMAs per algorithmic product
+            if mx:
+                roofline["kernel"] = ("conv_split2_kernel<9,...,TERMS=2> (fused GroupNorm+SiLU+conv3x3: fp16 hi*hi on v_mfma_f32_32x32x16_f16 + both cross terms in one "
+                                      "block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3), fp32 accumulate: 128 matrix-pipe cycles per 32x32x32 block instead of 192)")
+                roofline["matrix_pipe_cycles_vs_plain_f16"] = 2.0
+                roofline["executed_frac_of_f16_peak"] = round(2 * ach / peak, 4)
+            elif split:  # the matrix cores execute three f16 MFMAs per algorithmic product
                 roofline["executed_mfma_tflops"] = round(3 * ach, 2)
                 roofline["executed_frac_of_f16_peak"] = round(3 * ach / peak, 4)
                 roofline["fp32_mfma_peak_for_reference"] = FP32_MFMA_PEAK_TFLOPS
@@ -634,7 +640,7 @@ def main():
             # HBM traffic is a PMC quantity: it cannot be read from inside this process.  It is IMPORTED from the committed rocprofv3
             # --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/prof_round.sh -> profiles/rNN_pmc_hbm_traffic.json), per
             # launch of the dominant variant -- and only when that profile was taken on the kernel source this build was made from.
-            roofline.update(imported_traffic(split and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256)))
+            roofline.update(imported_traffic(split and not mx and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256)))
 
     chain_all = None
     if (world > 1 or dist is not None) and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_secondary:
@@ -653,7 +659,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "f16x3": "f32 via split f16x3 MFMA (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)",
-                      "f16": "f16 operands, fp32 accumulate (REDUCED PRECISION, ~1e-3 rel-L2: not the headline configuration)"}[args.precision],
+                      "f16": "f16 operands, fp32 accumulate (REDUCED PRECISION, ~1e-3 rel-L2: not the headline configuration)",
+                      "f16mx": "f32 via split f16 hi*hi + block-scaled fp8 (e4m3) cross terms on the GroupNorm-fed 3x3 convs, f16x3 elsewhere, fp32 accumulate "
+                               "(2.4e-5 .. 4e-5 rel-L2 per network against the reference: inside the 1e-4 contract, not the headline configuration)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": args.batch, "refmap": "3x128x128 (from 256x256 object images)" if args.workload == "estimate_chain" else f"3x{args.height}x{args.width}",
                        "weights": "seeded synthetic (no checkpoint offline)", "parallelism": f"batch-sharded x{world}, no collective",

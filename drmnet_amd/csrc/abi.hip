@@ -74,9 +74,11 @@ int with_scratch(hipStream_t s, Body&& body) {
 int g_op_precision = PREC_FP32;  // arithmetic used by the drm_op_* entry points (drm_set_op_precision)
 
 // packs one conv weight for the current op precision; `slot` = 64-float scale slot (2^k, 2^-k), `scratch` = 1 uint
-int pack_for_ops(const float* w, float* dst, float* slot, float* scratch, int cout, int cin, int taps, int coutp, int cinp, hipStream_t s) {
+int pack_for_ops(const float* w, float* dst, float* slot, float* scratch, int cout, int cin, int taps, int coutp, int cinp, hipStream_t s,
+                 bool mx_site = false) {
   if (g_op_precision != PREC_FP32 && cinp % 32 == 0)
-    return launch_pack_conv_weight_split(w, dst, slot, reinterpret_cast<unsigned*>(scratch), cout, cin, taps, coutp, cinp, s);
+    return launch_pack_conv_weight_split(w, dst, slot, reinterpret_cast<unsigned*>(scratch), cout, cin, taps, coutp, cinp, s,
+                                         g_op_precision == PREC_F16MX && mx_site);
   return launch_pack_conv_weight(w, dst, cout, cin, taps, coutp, cinp, s);
 }
 
@@ -270,10 +272,10 @@ int drm_op_resblock(const float* x0, int C0, int up0, const float* x1, int C1, c
           return DRM_OK;
         };
         DRM_TRY(cp(n1w, params[0], cin)); DRM_TRY(cp(n1b, params[1], cin));
-        DRM_TRY(pack_for_ops(params[2], c1w, s1, scratch, Cout, cin, 9, Cout, cin, s)); DRM_TRY(cp(c1b, params[3], Cout));
+        DRM_TRY(pack_for_ops(params[2], c1w, s1, scratch, Cout, cin, 9, Cout, cin, s, true)); DRM_TRY(cp(c1b, params[3], Cout));
         DRM_TRY(launch_linear(emb, params[4], params[5], e_out, N, emb_dim, Cout, 1, 0, s));
         DRM_TRY(cp(n2w, params[6], Cout)); DRM_TRY(cp(n2b, params[7], Cout));
-        DRM_TRY(pack_for_ops(params[8], c2w, s2, scratch, Cout, Cout, 9, Cout, Cout, s)); DRM_TRY(cp(c2b, params[9], Cout));
+        DRM_TRY(pack_for_ops(params[8], c2w, s2, scratch, Cout, Cout, 9, Cout, Cout, s, true)); DRM_TRY(cp(c2b, params[9], Cout));
         if (has_skip) {
           DRM_TRY(pack_for_ops(params[10], skw, s3, scratch, Cout, cin, 1, Cout, cin, s)); DRM_TRY(cp(skb, params[11], Cout));
         }
@@ -397,16 +399,16 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
 
 int drm_unet_set_precision(drm_unet* net, int precision) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(net && (precision == PREC_FP32 || precision == PREC_F16X3 || precision == PREC_F16),
-                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3) or 2 (plain fp16 operands)");
+    DRM_REQUIRE(net && (precision == PREC_FP32 || precision == PREC_F16X3 || precision == PREC_F16 || precision == PREC_F16MX),
+                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3), 2 (plain fp16 operands) or 3 (split fp16 with fp8 cross terms)");
     net->net.precision = precision;
     return DRM_OK;
   });
 }
 int drm_set_op_precision(int precision) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(precision == PREC_FP32 || precision == PREC_F16X3 || precision == PREC_F16,
-                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3) or 2 (plain fp16 operands)");
+    DRM_REQUIRE(precision == PREC_FP32 || precision == PREC_F16X3 || precision == PREC_F16 || precision == PREC_F16MX,
+                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3), 2 (plain fp16 operands) or 3 (split fp16 with fp8 cross terms)");
     g_op_precision = precision;
     return DRM_OK;
   });

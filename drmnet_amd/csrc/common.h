@@ -81,7 +81,8 @@ struct ConvArgs {
   size_t split_stride = 0;             // floats between the split-K slabs (0 unless ksplit > 1)
   double2* stat_part = nullptr;        // split-K reduction with statistics: [N][splitk_reduce_blocks][Cout] per-block sums ...
   unsigned* stat_ticket = nullptr;     // ... and [N] arrival counters (zero before the launch): the last block of an image folds its partials
-  int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 1 = plain fp16 operands
+  int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 2 = fp16 hi*hi + fp8 cross terms, 1 = plain fp16 operands
+  int mx_site = 0;                     // PREC_F16MX: this launch is one of the 3x3 convs whose weights carry the f16mx image
 #ifdef DRM_S2_STAMP
   unsigned* stamp_out = nullptr;       // diagnostic build: [8 waves][120][2] (id, s_memtime low word) of one workgroup
   int stamp_block = 0, stamp_tile0 = 0;
@@ -105,9 +106,11 @@ int splitk_reduce_blocks(int N, int H, int W);  // pixel blocks per image of the
 int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s);
 bool conv_split_fuses_stats();  // true when the active split kernel accumulates ConvArgs::stat_out in its epilogue
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);
+// mx: the f16mx image (fp16 hi planes + e4m3 planes of hi and lo) for the 3x3 convs that run with ConvArgs::terms == 2
 int launch_pack_conv_weight_split(const float* w, float* packed, float* scales, unsigned* scratch, int Cout, int Cin, int taps, int CoutP,
-                                  int CinP, hipStream_t s);
-enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
+                                  int CinP, hipStream_t s, bool mx = false);
+// PREC_F16MX: PREC_F16X3 with the GroupNorm-fed 3x3 convs on fp16 hi*hi + one block-scaled fp8 MFMA for both cross terms (~4e-5 per network)
+enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2, PREC_F16MX = 3 };
 // repack PyTorch conv weight [Cout][Cin][kh][kw] -> [taps][CinP/4][CoutP][4] (zero padded)
 int launch_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int taps, int CoutP, int CinP, hipStream_t s);
 size_t packed_conv_weight_floats(int taps, int CoutP, int CinP);

@@ -83,12 +83,41 @@ __global__ void pack_conv_weight_split_kernel(const float* __restrict__ w, _Floa
   }
 }
 
+// f16mx image (conv_split2.hip TERMS == 2): the hi planes as above; the four lo planes of every (tap, chunk) are replaced by the e4m3 images the
+// block-scaled MFMA reads -- plane 4 + g: bh8 = e4m3(hi / 2^6), plane 6 + g: bl8 = e4m3(lo * 2^6) of the 16 channels of group g, one byte each
+// (16 bytes per cout and plane, the same footprint).  |hi| < 2^14 and |lo| <= 4 by the pre-scaling, so both stay inside e4m3's +-448.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__global__ void pack_conv_weight_mx_kernel(const float* __restrict__ w, unsigned char* __restrict__ p, const float* __restrict__ scales, int Cout, int Cin,
+                                           int taps, int CoutP, int CinP) {
+  const int nchunks = CinP / 32;
+  const size_t total = (size_t)taps * nchunks * 4 * CoutP * 16;  // bytes of the lo halves
+  const float scale = scales[0];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i % 16;
+    size_t t = i / 16;
+    const int co = t % CoutP; t /= CoutP;
+    const int g = t % 2; t /= 2;
+    const int blk = t % 2; t /= 2;
+    const int q = t % nchunks;
+    const int tap = t / nchunks;
+    const int ci = 32 * q + 16 * g + j;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * taps + tap] * scale;
+    const _Float16 hi = (_Float16)v;
+    const float x = blk ? (v - (float)hi) : (float)hi;
+    s16x2_t z = {0, 0};
+    z = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(z, x, 0.f, blk ? (1.0f / 64.0f) : 64.0f, false);
+    // byte address: ((tap * nchunks + q) * 8 + 4 + 2 * blk + g) planes of CoutP 16-byte entries
+    p[((((size_t)tap * nchunks + q) * 8 + 4 + 2 * blk + g) * CoutP + co) * 16 + j] = (unsigned char)(z[0] & 0xff);
+  }
+}
+
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP) {
   return (size_t)taps * CoutP * CinP;  // hi + lo fp16 = 4 bytes per weight, same footprint as fp32
 }
 
 int launch_pack_conv_weight_split(const float* w, float* packed, float* scales /*[2] device*/, unsigned* scratch /*1 uint device*/, int Cout,
-                                  int Cin, int taps, int CoutP, int CinP, hipStream_t s) {
+                                  int Cin, int taps, int CoutP, int CinP, hipStream_t s, bool mx) {
   DRM_REQUIRE(CinP % 32 == 0 && CoutP >= Cout && CinP >= Cin, "pack_conv_weight_split padding");
   const size_t n = (size_t)Cout * Cin * taps;
   DRM_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(unsigned), s));
@@ -100,6 +129,12 @@ int launch_pack_conv_weight_split(const float* w, float* packed, float* scales /
   hipLaunchKernelGGL(pack_conv_weight_split_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w,
                      reinterpret_cast<_Float16*>(packed), scales, Cout, Cin, taps, CoutP, CinP);
   DRM_HIP_CHECK(hipGetLastError());
+  if (mx) {  // (overwrites the lo planes the launch above filled)
+    const size_t bytes = (size_t)taps * CoutP * CinP * 2;
+    hipLaunchKernelGGL(pack_conv_weight_mx_kernel, dim3((unsigned)std::min<size_t>((bytes + 255) / 256, 4096)), dim3(256), 0, s, w,
+                       reinterpret_cast<unsigned char*>(packed), scales, Cout, Cin, taps, CoutP, CinP);
+    DRM_HIP_CHECK(hipGetLastError());
+  }
   return DRM_OK;
 }
 

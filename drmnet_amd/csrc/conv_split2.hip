@@ -52,6 +52,26 @@ namespace drm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// TERMS == 2 ("f16mx"): a*b ~ ah*bh (two v_mfma_f32_32x32x16_f16 per 32-channel chunk, as in every fp16 mode) + (al*bh + ah*bl) in ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4: its K = 64 is two 32-element scale blocks, block 0 = [al8 | bh8], block 1 = [ah8 | bl8] over the chunk's 32
+// channels, operands OCP e4m3 with a power-of-two (E8M0) factor per block.  128 matrix-pipe cycles per (tap, chunk, 32x32 block) instead of 192.
+// The cross terms are 2^-11 of the product and carry the 2^-4 rounding of an e4m3 factor: ~1e-5 per conv, ~4e-5 through a network (the
+// exact split is ~1e-6) -- inside the 1e-4 bar the hot path is held to, outside the 2e-5 the f16x3 mode is tested at.
+// Operand layout measured with tools/mx_probe.hip: lane (r, h) supplies 32 bytes; bytes 0-15 of BOTH lane halves form scale block 0
+// (factor taken from lanes 0-31), bytes 16-31 form block 1 (factor from lanes 32-63).
+// Ranges: the staged activation is clamped to +-MX_A_LIM (GroupNorm + SiLU outputs: nothing gets near), weights are pre-scaled to max |w| in
+// [2^13, 2^14) by the packer; the factors below put every fp8 operand inside +-448 (v_cvt_scalef32_pk_fp8_f32 makes NaN above that).
+constexpr int MX_EA = 11;                        // staged activations: |v| <= 448 * 2^(EA-8) = 3584
+constexpr float MX_A_LIM = 3584.0f;
+constexpr float MX_AH_DIV = 8.0f;                // ah8 = v / 2^(EA-8)
+constexpr float MX_AL_DIV = 1.0f / 256.0f;       // al8 = (v - ah) / 2^(EA-19)   (|v - ah| <= 2^(EA-11))
+constexpr int MX_SA_AL = 127 + MX_EA - 19, MX_SA_AH = 127 + MX_EA - 8;  // E8M0 factors of A's two blocks
+constexpr float MX_BH_DIV = 64.0f;               // bh8 = bh / 2^6 (|bh| < 2^14), bl8 = bl * 2^6 (|bl| <= 4)
+constexpr float MX_BL_DIV = 1.0f / 64.0f;
+constexpr int MX_SB_BH = 127 + 6, MX_SB_BL = 127 - 6;
 
 template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
 struct S2Cfg {
@@ -113,7 +133,8 @@ struct S2Cfg {
   }
   static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
   static_assert(B_DMA_F4 % 64 == 0 && B_PER >= 1, "whole 1-KiB LDS-DMA instructions; a wave issues B_PER of them or none");
-  static_assert(TERMS == 3 || TERMS == 1 || TERMS == 0, "3 = fp16 hi/lo split (fp32 accuracy), 1 = plain fp16 operands, 0 = fp32 operands (exact fp32 MFMA)");
+  static_assert(TERMS == 3 || TERMS == 2 || TERMS == 1 || TERMS == 0,
+                "3 = fp16 hi/lo split (fp32 accuracy), 2 = fp16 hi*hi + both cross terms in one block-scaled fp8 MFMA, 1 = plain fp16 operands, 0 = fp32 operands (exact fp32 MFMA)");
   static_assert(TERMS == 1 || B_DMA_F4 % NTHR == 0, "split mode: every wave owns the same number of distinct 1-KiB pieces");
   static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
   static_assert(R >= 2, "ring needs >= 2 slots");
@@ -341,6 +362,28 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         // 2 * l_o and 2 * l_o + 1), the same bytes per element as the hi + lo halves
         areg[j][0] = ok ? f32x4{v[0], v[1], v[2], v[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
         areg[j][1] = ok ? f32x4{v[4], v[5], v[6], v[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else if constexpr (TERMS == 2) {
+        // eight fp16 hi halfs + the two fp8 images of the octet: al8 = e4m3((v - hi) * 2^(19-EA)), ah8 = e4m3(v * 2^(8-EA))
+        F4H8b hi;
+        float c8[8], l8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          c8[k] = __builtin_amdgcn_fmed3f(ok ? v[k] : 0.f, -MX_A_LIM, MX_A_LIM);
+          hi.h8[k] = (_Float16)c8[k];
+          l8[k] = c8[k] - (float)hi.h8[k];
+        }
+        s16x2 q[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          s16x2 z = {0, 0};
+          z = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(z, l8[4 * k], l8[4 * k + 1], MX_AL_DIV, false);
+          q[k] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(z, l8[4 * k + 2], l8[4 * k + 3], MX_AL_DIV, true);
+          s16x2 y = {0, 0};
+          y = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(y, c8[4 * k], c8[4 * k + 1], MX_AH_DIV, false);
+          q[2 + k] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(y, c8[4 * k + 2], c8[4 * k + 3], MX_AH_DIV, true);
+        }
+        areg[j][0] = f32x4{hi.f4.x, hi.f4.y, hi.f4.z, hi.f4.w};
+        areg[j][1] = f32x4{__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]), __builtin_bit_cast(float, q[2]), __builtin_bit_cast(float, q[3])};
       } else {
         F4H8b hi, lo;
 #pragma unroll
@@ -365,6 +408,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       if constexpr (TERMS == 0) {
         Ad[(2 * l_o) * C::HPS + pixel] = w0;
         Ad[(2 * l_o + 1) * C::HPS + pixel] = w1;
+      } else if constexpr (TERMS == 2) {
+        // hi plane as in every fp16 mode; planes 4 + g (al8) and 6 + g (ah8) hold the 16 channels of group g = octet / 2, one byte each:
+        // this octet owns 8 bytes of either
+        Ad[l_o * C::HPS + pixel] = w0;
+        reinterpret_cast<float2*>(Ad + (4 + (l_o >> 1)) * C::HPS + pixel)[l_o & 1] = make_float2(w1.x, w1.y);
+        reinterpret_cast<float2*>(Ad + (6 + (l_o >> 1)) * C::HPS + pixel)[l_o & 1] = make_float2(w1.z, w1.w);
       } else {
         Ad[l_o * C::HPS + pixel] = w0;
         if (TERMS == 3) Ad[(4 + l_o) * C::HPS + pixel] = w1;
@@ -532,6 +581,51 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           if (j == 0 || j == 2) {
             __builtin_amdgcn_sched_barrier(0);
             hook(j >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        return;
+      }
+      if constexpr (TERMS == 2) {
+        // both cross terms of the chunk: lane half h reads the al8 / ah8 (bh8 / bl8) planes of channel group h
+        {
+          i32x8 am[MT], bm[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const float4 p0 = Ab[(4 + h) * C::HPS + a_base[i] + tapoff], p1 = Ab[(6 + h) * C::HPS + a_base[i] + tapoff];
+            am[i] = i32x8{__builtin_bit_cast(int, p0.x), __builtin_bit_cast(int, p0.y), __builtin_bit_cast(int, p0.z), __builtin_bit_cast(int, p0.w),
+                          __builtin_bit_cast(int, p1.x), __builtin_bit_cast(int, p1.y), __builtin_bit_cast(int, p1.z), __builtin_bit_cast(int, p1.w)};
+          }
+#pragma unroll
+          for (int c = 0; c < NT; ++c) {
+            const float4 p0 = Bc[(4 + h) * C::BN + b_base[c]], p1 = Bc[(6 + h) * C::BN + b_base[c]];
+            bm[c] = i32x8{__builtin_bit_cast(int, p0.x), __builtin_bit_cast(int, p0.y), __builtin_bit_cast(int, p0.z), __builtin_bit_cast(int, p0.w),
+                          __builtin_bit_cast(int, p1.x), __builtin_bit_cast(int, p1.y), __builtin_bit_cast(int, p1.z), __builtin_bit_cast(int, p1.w)};
+          }
+          const int sa = h ? MX_SA_AH : MX_SA_AL, sb = h ? MX_SB_BL : MX_SB_BH;
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[i][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(am[i], bm[c], acc[i][c], 0, 0, 0, sa, 0, sb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hook(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int seg = s2 * 2 + h;
+          F4H8b ah[MT], bh[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) ah[i].f4 = Ab[seg * C::HPS + a_base[i] + tapoff];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) bh[c].f4 = Bc[seg * C::BN + b_base[c]];
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+          if (s2 == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            hook(1);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -1021,7 +1115,7 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
   }
   // (one round of 128-wide tiles on >= 176 of the 256 CUs beats two rounds of the less efficient 64-wide ones: qkv 640->1920 @8x16 27 %,
   //  512->1536 @8x16 24 %, 3x3 384->384 @16x32 12 % faster than with the old "fill every CU" rule)
-  if constexpr (TAPS == 9 && TH == 16 && TW == 16 && TERMS == 3) {
+  if constexpr (TAPS == 9 && TH == 16 && TW == 16 && (TERMS == 3 || TERMS == 2)) {
     // 3x3 with 192 output channels per tile (64 x 96 per wave; one-tap weight ring of 3: the three-tap groups would not fit next to the
     // halo tile) for Cout = 384 on big maps: 12 fragment reads per 18 MFMA products instead of 8 per 12 -- 5 % faster there.  Fits since
     // the scalar-base DMA addressing took the kernel from 256 to 207 VGPRs.
@@ -1300,6 +1394,10 @@ int launch_conv_split2(const ConvArgs& a, hipStream_t s) {
   if (a.terms == 1) {  // plain fp16 operands, one MFMA per product (DRM_PREC_F16)
     if (a.taps == 9) return dispatch_s2_tile<9, 1>(a, s);
     return dispatch_s2_tile<1, 1>(a, s);
+  }
+  if (a.terms == 2) {  // fp16 hi*hi + block-scaled fp8 cross terms (DRM_PREC_F16MX): the GroupNorm-fed 3x3 convs only
+    DRM_REQUIRE(a.taps == 9 && a.gn_scale && !a.in_inv && a.w_img_stride_f4 == 0, "f16mx: 3x3 convs on a GroupNorm-ed input only");
+    return dispatch_s2_tile<9, 2>(a, s);
   }
   if (a.taps == 9) return dispatch_s2_tile<9, 3>(a, s);
   return dispatch_s2_tile<1, 3>(a, s);

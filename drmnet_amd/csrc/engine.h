@@ -76,6 +76,7 @@ struct ParamSlot {
   size_t count = 0;        // floats copied (PK_COPY)
   int cout = 0, cin = 0, taps = 0, coutp = 0, cinp = 0;  // PK_CONV
   size_t scale_dst = 0;    // PK_CONV: 2 floats (2^k, 2^-k) of the split-precision weight pre-scaling
+  bool mx_site = false;    // PK_CONV: a GroupNorm-fed 3x3 conv of a res block (PREC_F16MX packs the f16mx image for it)
 };
 
 struct ResLayer {
@@ -125,7 +126,7 @@ class UNet {
 
  private:
   size_t add_copy(const std::string& name, std::vector<int64_t> shape, size_t padded_count = 0);
-  size_t add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d = false, size_t* scale_off = nullptr);
+  size_t add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d = false, size_t* scale_off = nullptr, bool mx_site = false);
   void add_res(Layer& l, const std::string& prefix, int cin, int cout);
   void add_attn(Layer& l, const std::string& prefix, int ch);
 };
@@ -137,8 +138,10 @@ struct Ctx {
   int N;
   int precision = PREC_FP32;
   bool dry() const { return ar->dry; }
-  bool split() const { return precision == PREC_F16X3 || precision == PREC_F16; }
-  int terms() const { return precision == PREC_F16 ? 1 : (precision == PREC_FP32 ? 0 : 3); }  // ConvArgs::terms of the pipeline kernel
+  bool split() const { return precision == PREC_F16X3 || precision == PREC_F16 || precision == PREC_F16MX; }
+  // ConvArgs::terms of the pipeline kernel (PREC_F16MX: 3, and 2 on its mx_site launches)
+  int terms() const { return precision == PREC_F16 ? 1 : (precision == PREC_FP32 ? 0 : 3); }
+  bool mx() const { return precision == PREC_F16MX; }
 };
 Act new_act(Ctx& c, int C, int H, int W);
 int ensure_moments(Ctx& c, Act& a);

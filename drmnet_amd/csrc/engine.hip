@@ -81,13 +81,14 @@ size_t UNet::add_copy(const std::string& name, std::vector<int64_t> shape, size_
   return p.dst;
 }
 
-size_t UNet::add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d, size_t* scale_off) {
+size_t UNet::add_conv(const std::string& name, int cout, int cin, int k, int coutp, int cinp, bool conv1d, size_t* scale_off, bool mx_site) {
   ParamSlot p;
   p.name = name;
   if (conv1d) p.shape = {cout, cin, k};
   else p.shape = {cout, cin, k, k};
   p.kind = PK_CONV;
   p.cout = cout; p.cin = cin; p.taps = conv1d ? k : k * k; p.coutp = coutp; p.cinp = cinp;
+  p.mx_site = mx_site;
   p.dst = wbuf_floats;
   wbuf_floats += (packed_conv_weight_floats(p.taps, coutp, cinp) + 63) & ~size_t(63);
   p.scale_dst = wbuf_floats;
@@ -103,7 +104,7 @@ void UNet::add_res(Layer& l, const std::string& px, int cin, int cout) {
   r.cin = cin; r.cout = cout; r.has_skip = (cin != cout);
   r.n1_w = add_copy(px + ".in_layers.0.weight", {cin});
   r.n1_b = add_copy(px + ".in_layers.0.bias", {cin});
-  r.c1_w = add_conv(px + ".in_layers.2.weight", cout, cin, 3, cout, cin, false, &r.c1_s);
+  r.c1_w = add_conv(px + ".in_layers.2.weight", cout, cin, 3, cout, cin, false, &r.c1_s, true);
   r.c1_b = add_copy(px + ".in_layers.2.bias", {cout});
   r.emb_off = emb_total;
   emb_total += cout;
@@ -114,7 +115,7 @@ void UNet::add_res(Layer& l, const std::string& px, int cin, int cout) {
   params.push_back(eb);
   r.n2_w = add_copy(px + ".out_layers.0.weight", {cout});
   r.n2_b = add_copy(px + ".out_layers.0.bias", {cout});
-  r.c2_w = add_conv(px + ".out_layers.3.weight", cout, cout, 3, cout, cout, false, &r.c2_s);
+  r.c2_w = add_conv(px + ".out_layers.3.weight", cout, cout, 3, cout, cout, false, &r.c2_s, true);
   r.c2_b = add_copy(px + ".out_layers.3.bias", {cout});
   if (r.has_skip) {
     r.sk_w = add_conv(px + ".skip_connection.weight", cout, cin, 1, cout, cin, false, &r.sk_s);
@@ -255,7 +256,7 @@ int UNet::load(const float* const* ptrs, int count, hipStream_t s, int set) {
       DRM_HIP_CHECK(hipMemcpyAsync(wbuf + p.dst, ptrs[i], p.count * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else if (precision != PREC_FP32 && p.cinp % 32 == 0) {  // both fp16 modes use the pre-split, pre-scaled image
       DRM_TRY(launch_pack_conv_weight_split(ptrs[i], wbuf + p.dst, wbuf + p.scale_dst, reinterpret_cast<unsigned*>(wbuf + scratch_off), p.cout,
-                                            p.cin, p.taps, p.coutp, p.cinp, s));
+                                            p.cin, p.taps, p.coutp, p.cinp, s, precision == PREC_F16MX && p.mx_site));
     } else {
       DRM_TRY(launch_pack_conv_weight(ptrs[i], wbuf + p.dst, p.cout, p.cin, p.taps, p.coutp, p.cinp, s));
     }
@@ -312,7 +313,7 @@ float* plan_splitk(Ctx& c, ConvArgs& a) {
 int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_for, float* splitk_ws) {
   if (on_pipeline(c, a)) {
     a.w_inv_scale = c.split() ? Wb + scale_off + 1 : nullptr;  // (fp32 weights are packed unscaled)
-    a.terms = c.terms();
+    a.terms = (c.mx() && a.mx_site) ? 2 : c.terms();
     if (!splitk_ws) {
       a.ksplit = 1;
       a.split_stride = 0;
@@ -407,7 +408,7 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
   DRM_TRY(gn_params(c, x0, x1, Wb + r.n1_w, Wb + r.n1_b, sc1, sh1, r.has_skip ? &k : nullptr));
   ConvArgs a;  // in_layers conv: GroupNorm(x0 | x1) -> SiLU -> 3x3 + emb
   a.src0 = x0.p; a.src1 = x1 ? x1->p : nullptr; a.C0 = C0; a.C1 = C1; a.up0 = x0.up;
-  a.N = c.N; a.H = H; a.W = W; a.taps = 9; a.Cout = r.cout;
+  a.N = c.N; a.H = H; a.W = W; a.taps = 9; a.Cout = r.cout; a.mx_site = 1;
   float* ws1 = plan_splitk(c, a);
   if (!c.dry()) {
     a.gn_scale = sc1; a.gn_shift = sh1; a.silu = 1;
@@ -418,7 +419,7 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
   }
   DRM_TRY(gn_params(c, h1, nullptr, Wb + r.n2_w, Wb + r.n2_b, sc2, sh2));
   ConvArgs b;  // out_layers conv: GroupNorm(h1) -> SiLU -> 3x3 + residual
-  b.src0 = h1.p; b.C0 = r.cout; b.N = c.N; b.H = H; b.W = W; b.taps = 9; b.Cout = r.cout;
+  b.src0 = h1.p; b.C0 = r.cout; b.N = c.N; b.H = H; b.W = W; b.taps = 9; b.Cout = r.cout; b.mx_site = 1;
   float* ws2 = plan_splitk(c, b);
   float* wsk = nullptr;
   if (r.has_skip) {

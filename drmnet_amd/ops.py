@@ -14,7 +14,7 @@ from . import _lib
 
 def set_precision(precision: str) -> None:
     """Arithmetic of the drm_op_* entry points: "fp32" (default) or "f16x3" (split fp16, fp32-accurate)."""
-    modes = {"fp32": 0, "f16x3": 1, "f16": 2}
+    modes = {"fp32": 0, "f16x3": 1, "f16": 2, "f16mx": 3}
     if precision not in modes:
         raise ValueError(f"precision must be one of {list(modes)}")
     _lib.check(_lib.lib().drm_set_op_precision(modes[precision]))

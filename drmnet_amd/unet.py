@@ -137,7 +137,7 @@ class _HipUNetBase(nn.Module):
             pass
 
     # ------------------------------------------------------------------ arithmetic mode
-    PRECISIONS = {"fp32": 0, "f16x3": 1, "f16": 2}
+    PRECISIONS = {"fp32": 0, "f16x3": 1, "f16": 2, "f16mx": 3}
 
     def set_precision(self, precision: str) -> "._HipUNetBase":
         """"fp32": exact fp32 products on v_mfma_f32_32x32x2_f32 (default).

@@ -1,0 +1,111 @@
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// fp8 e4m3 encode of small exactly-representable values
+__host__ __device__ inline unsigned char enc_e4m3(float v) {
+  if (v == 0.f) return 0;
+  unsigned char s = v < 0 ? 0x80 : 0; float a = fabsf(v);
+  int e; float m = frexpf(a, &e);  // a = m * 2^e, m in [0.5,1)
+  int E = e - 1 + 7;               // exponent of 1.xxx form, bias 7
+  float frac = m * 2.f - 1.f;      // [0,1)
+  int M = (int)lrintf(frac * 8.f);
+  if (M == 8) { M = 0; ++E; }
+  if (E <= 0) { // subnormal: value = M/8 * 2^-6
+    M = (int)lrintf(a / ldexpf(1.f, -6) * 8.f); return s | (unsigned char)M;
+  }
+  return s | (unsigned char)((E << 3) | M);
+}
+
+__global__ void k_sem(const unsigned char* A, const unsigned char* B, float* D, int sa, int sb) {
+  // A: [32 rows][64 k] bytes row-major; B: [64 k][32 cols] bytes (k-major)
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  i32x8 a, b;
+  unsigned char ab[32], bb[32];
+  for (int j = 0; j < 32; ++j) { ab[j] = A[r * 64 + 32 * h + j]; bb[j] = B[(32 * h + j) * 32 + r]; }
+  for (int q = 0; q < 8; ++q) {
+    a[q] = ab[4*q] | (ab[4*q+1] << 8) | (ab[4*q+2] << 16) | (ab[4*q+3] << 24);
+    b[q] = bb[4*q] | (bb[4*q+1] << 8) | (bb[4*q+2] << 16) | (bb[4*q+3] << 24);
+  }
+  f32x16 c; for (int e = 0; e < 16; ++e) c[e] = 0.f;
+  // scale registers: E8M0 in byte 0; lanes of half h use (h ? sb_hi : ...) -- pass per-half scale via sa/sb: low byte for h=0, next byte for h=1
+  const int scale_a = (h == 0) ? (sa & 0xff) : ((sa >> 8) & 0xff);
+  const int scale_b = (h == 0) ? (sb & 0xff) : ((sb >> 8) & 0xff);
+  c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, scale_b);
+  for (int e = 0; e < 16; ++e) { const int row = (e & 3) + 8 * (e >> 2) + 4 * h; D[row * 32 + r] = c[e]; }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_rate(float* out, int iters) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  i32x8 a8, b8; f16x8 ah, bh;
+  for (int q = 0; q < 8; ++q) { a8[q] = 0x38383838 + threadIdx.x * 0x01010101 + q; b8[q] = 0x3c3c3c3c + q * 0x01000100; ah[q] = (_Float16)(1.0f + 0.001f * threadIdx.x + q); bh[q] = (_Float16)(0.5f + q); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (MODE == 0) {  // f16x3 pattern per 32-channel chunk: 6 f16 MFMAs
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+      } else {          // hybrid: 2 f16 MFMAs + 1 MX fp8 K=64
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i], 0, 0, 0, 115, 0, 127);
+      }
+    }
+  }
+  float s = 0.f; for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+int main() {
+  // ---- semantics
+  std::vector<unsigned char> hA(32 * 64), hB(64 * 32);
+  std::vector<float> fA(32 * 64), fB(64 * 32);
+  unsigned seed = 7; auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (int)((seed >> 16) % 9) - 4; };
+  for (int i = 0; i < 32 * 64; ++i) { fA[i] = rnd() * 0.5f; hA[i] = enc_e4m3(fA[i]); }
+  for (int i = 0; i < 64 * 32; ++i) { fB[i] = rnd() * 0.25f; hB[i] = enc_e4m3(fB[i]); }
+  unsigned char *dA, *dB; float* dD; hipMalloc(&dA, hA.size()); hipMalloc(&dB, hB.size()); hipMalloc(&dD, 32 * 32 * 4);
+  hipMemcpy(dA, hA.data(), hA.size(), hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size(), hipMemcpyHostToDevice);
+  for (int trial = 0; trial < 5; ++trial) {
+    // E8M0 block scales: low byte = lanes 0..31 (k-half 0), next byte = lanes 32..63 (k-half 1)
+    const int SA[5] = {127 | (127 << 8), 124 | (124 << 8), 124 | (127 << 8), 127 | (127 << 8), 124 | (127 << 8)};
+    const int SB[5] = {127 | (127 << 8), 127 | (127 << 8), 127 | (127 << 8), 127 | (129 << 8), 127 | (129 << 8)};
+    const int sa = SA[trial], sb = SB[trial];
+    hipLaunchKernelGGL(k_sem, dim3(1), dim3(64), 0, 0, dA, dB, dD, sa, sb);
+    std::vector<float> hD(32 * 32); hipMemcpy(hD.data(), dD, hD.size() * 4, hipMemcpyDeviceToHost);
+    // least-squares fit D = sum_q c[q] * P_q over the four quarter sums P_q, q = 2 * h + (byte >= 16): k = 32 h + j, j < 16 or j >= 16
+    double G[4][5] = {};
+    std::vector<double> P(4 * 1024);
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
+      double p[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 64; ++k) p[k >> 4] += (double)fA[i * 64 + k] * fB[k * 32 + j];
+      for (int q = 0; q < 4; ++q) { P[q * 1024 + i * 32 + j] = p[q]; for (int q2 = 0; q2 < 4; ++q2) G[q][q2] += p[q] * p[q2]; G[q][4] += p[q] * hD[i * 32 + j]; }
+    }
+    for (int c = 0; c < 4; ++c) {  // Gauss-Jordan
+      const double d = G[c][c]; for (int e = 0; e < 5; ++e) G[c][e] /= d;
+      for (int r2 = 0; r2 < 4; ++r2) if (r2 != c) { const double f = G[r2][c]; for (int e = 0; e < 5; ++e) G[r2][e] -= f * G[c][e]; }
+    }
+    double res = 0;
+    for (int e = 0; e < 1024; ++e) { double v = 0; for (int q = 0; q < 4; ++q) v += G[q][4] * P[q * 1024 + e]; res = fmax(res, fabs(v - hD[e])); }
+    printf("semantics trial %d: scale_a (lanes<32: %d, lanes>=32: %d) scale_b (%d, %d): weights of the quarter sums [h0 b0-15, h0 b16-31, h1 b0-15, h1 b16-31] = %.4g %.4g %.4g %.4g, max residual %g\n",
+           trial, sa & 255, (sa >> 8) & 255, sb & 255, (sb >> 8) & 255, G[0][4], G[1][4], G[2][4], G[3][4], res);
+  }
+  // ---- rate
+  float* out; hipMalloc(&out, 256 * 512 * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int mode = 0; mode < 2; ++mode) for (int rep = 0; rep < 3; ++rep) {
+    const int iters = 20000;
+    hipEventRecord(e0);
+    if (mode == 0) hipLaunchKernelGGL(k_rate<0>, dim3(256), dim3(512), 0, 0, out, iters); else hipLaunchKernelGGL(k_rate<1>, dim3(256), dim3(512), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double chunks = 256.0 * 8 * iters * 4;  // (wave, 32x32 block, 32-channel chunk) units
+    printf("mode %d (%s): %.3f ms, %.2f G chunk-blocks/s  -> algorithmic %.0f TFLOP/s\n", mode, mode ? "2 f16 + 1 MX-fp8 K=64" : "6 f16 (f16x3)", ms, chunks / ms * 1e-6, chunks * 2.0 * 32 * 32 * 32 / (ms * 1e-3) / 1e12);
+  }
+  return 0;
+}
