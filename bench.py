@@ -49,9 +49,11 @@ def parse():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim", "obsnet_ddim_chain", "estimate_chain"])
-    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "f16", "f16mx"],
-                    help="conv arithmetic: f16x3 (default) = every fp32 operand split into fp16 hi+lo, 3 MFMAs per product, fp32 "
-                         "accumulate: passes the SAME parity tolerances as fp32 (tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--precision", default="f16mx", choices=["fp32", "f16x3", "f16", "f16mx"],
+                    help="conv arithmetic: f16mx (default) = fp32 operands split into fp16 hi+lo; hi*hi on the f16 MFMA, both cross terms of the "
+                         "GroupNorm-fed 3x3 convs in one block-scaled fp8 MFMA (2.4e-5 .. 4e-5 rel-L2 per network against the reference, 1e-4 contract: "
+                         "tests/test_gpu_f16mx.py); f16x3 = all three products on the f16 MFMA (~2e-6: passes the SAME tolerances as fp32, "
+                         "tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32; f16 = reduced precision (~1e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-strict-fp32", action="store_true", help="skip the short exact-fp32 pass that follows the headline measurement")
@@ -257,7 +259,8 @@ def cpu_baseline(args):
     return {"value": round(n / dt, 4), "unit": "U-Net denoise steps/sec", "cores": threads, "kind": "port",
             "sample": f"{n} DRMNet reverse steps (RefNet+IllNet, fp32) of 1 refmap 3x{H}x{W}, oracle/ on host CPU, {dt:.1f}s"}
 
-DOMINANT_VARIANT = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3, false>"
+DOMINANT_VARIANTS = {"f16x3": "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3, false>",
+                     "f16mx": "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 2, false>"}
 
 
 def kernel_source_hash() -> str:
@@ -267,13 +270,14 @@ def kernel_source_hash() -> str:
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def imported_traffic(applicable: bool) -> dict:
+def imported_traffic(applicable: bool, precision: str = "f16x3") -> dict:
     import glob
 
     out = {"traffic": None}
-    if not applicable:
+    DOMINANT_VARIANT = DOMINANT_VARIANTS.get(precision)
+    if not applicable or DOMINANT_VARIANT is None:
         return out
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 prof = json.load(f)
@@ -331,10 +335,10 @@ def self_launch(args) -> int:
     return rc
 
 
-def strict_fp32_pass(args, model, dev, L, _lib):
-    """The same workload in exact-fp32 arithmetic (v_mfma_f32_32x32x2_f32), a short untimed-region pass run AFTER the headline
-    measurement so the driver's record carries both numbers (the headline is the fp32-accurate split mode)."""
-    model.set_precision("fp32")
+def strict_fp32_pass(args, model, dev, L, _lib, precision="fp32"):
+    """The same workload in exact-fp32 arithmetic (v_mfma_f32_32x32x2_f32) -- or, with precision="f16x3", in the three-product split mode --
+    a short pass run AFTER the headline measurement so the driver's record carries every accurate mode's number next to the headline's."""
+    model.set_precision(precision)
     step, gflop, _ = make_step(args, model, dev)
     for _ in range(2):
         step()
@@ -354,6 +358,12 @@ def strict_fp32_pass(args, model, dev, L, _lib):
     tm, tf, tb, tn = (C.c_double * K0)(), (C.c_double * K0)(), (C.c_double * K0)(), (C.c_int64 * K0)()
     _lib.check(L.drm_profile_collect(tm, tf, tb, tn))
     ach = tf[0] / (tm[0] * 1e-3) / 1e12 if tm[0] > 0 else None
+    if precision == "f16x3":
+        return {"value": round(args.batch * n / dt, 3), "unit": "denoise steps/sec (samples x steps / s)", "steps": n, "ms_per_step": round(dt / n * 1e3, 3),
+                "dtype": "f32 via split f16x3 MFMA (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate; ~2e-6 rel-L2 against the reference)",
+                "roofline": None if ach is None else {"bound": "mfma", "kernel": "conv_split2_kernel<9,...,TERMS=3>", "achieved": round(ach, 2), "peak": F16_MFMA_PEAK_TFLOPS,
+                                                      "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4), "executed_frac_of_f16_peak": round(3 * ach / F16_MFMA_PEAK_TFLOPS, 4),
+                                                      "avg_launch_ms": round(tm[0] / max(tn[0], 1), 4)}}
     return {"value": round(args.batch * n / dt, 3), "unit": "denoise steps/sec (samples x steps / s)", "steps": n, "ms_per_step": round(dt / n * 1e3, 3),
             "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)",
             "roofline": None if ach is None else {"bound": "mfma", "kernel": "conv_split2_kernel<9,...,TERMS=0> (the same LDS-DMA pipeline kernel on fp32 operands, v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
@@ -396,11 +406,12 @@ def secondary_pass(args, model, dev):
     torch.cuda.empty_cache()
 
     # ---- ObsNet DDIM-50 chain, batch 256 @3x128x256 (BASELINE configs[2])
-    obs = build_models("obsnet", dev, "f16x3")
+    acc = args.precision  # the accurate mode the headline ran in
+    obs = build_models("obsnet", dev, acc)
     x = synth.synth_refmaps(256, 128, 256, synth.SEED_INPUT).to(dev)
     xT = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
     chains = {}
-    for prec in ("f16x3", "f16"):
+    for prec in ((acc, "f16x3", "f16") if acc != "f16x3" else ("f16x3", "f16")):
         obs.set_precision(prec)
         smp = DDIMSampler(obs)
         smp.make_schedule(50, ddim_eta=1.0, verbose=False)
@@ -418,7 +429,7 @@ def secondary_pass(args, model, dev):
     # the literal wording of configs[1] ("reverse DDPM 1000-step, batch 32"): the only 1000-step schedule of the reference is ObsNet's ancestral
     # sampler: 100 of its 1000 steps through the device loop (the per-step cost does not depend on t), fp32-accurate mode
     try:
-        obs.set_precision("f16x3")
+        obs.set_precision(acc)
         x32, xT32 = x[:32].contiguous(), xT[:32].contiguous()
         res = {}
 
@@ -427,17 +438,17 @@ def secondary_pass(args, model, dev):
 
         dt = timed(ddpm, 1, warm=1)
         out["obsnet_ancestral_ddpm_b32_3x128x256"] = {"value": round(32 * 100 / dt, 1), "unit": unit, "s_per_100_steps": round(dt, 3), "steps_timed": 100,
-                                                     "of_schedule": 1000, "finite": bool(torch.isfinite(res["x"]).all().item()), "precision": "f16x3"}
+                                                     "of_schedule": 1000, "finite": bool(torch.isfinite(res["x"]).all().item()), "precision": acc}
     except Exception as e:  # noqa: BLE001
         out["obsnet_ancestral_ddpm_b32_3x128x256"] = {"error": f"{type(e).__name__}: {e}"}
-    chains["note"] = ("f16x3 = fp32-accurate split mode (1e-4 contract); f16 = fp16 operands, fp32 accumulate: the reduced-precision mode standing in for "
+    chains["note"] = ("f16mx / f16x3 = the two accurate split modes (1e-4 contract; cross terms on the block-scaled fp8 MFMA / on the f16 MFMA); f16 = fp16 operands, fp32 accumulate: the reduced-precision mode standing in for "
                       "configs[2]'s bf16 (more mantissa, guarded range; 5e-3 tolerance, tests/test_gpu_configs.py)")
     out["obsnet_ddim50_chain_b256_3x128x256"] = chains
     del x, xT
     torch.cuda.empty_cache()
 
     # ---- full chain (BASELINE configs[4]; metric part 2): 32 object images per GPU, 256x256 -> 128x128 refmaps
-    obs.set_precision("f16x3")
+    obs.set_precision(acc)
     obs.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["data"]["params"]["predict"])
     model.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/drmnet/eval_drmnet.yaml"))["data"]["params"]["predict"])
     B = 32
@@ -490,7 +501,7 @@ def full_chain_all_ranks(args, model, dev, dist):
 
     B, err, run = 32, None, None
     try:
-        obs = build_models("obsnet", dev, "f16x3")
+        obs = build_models("obsnet", dev, args.precision)
         obs.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["data"]["params"]["predict"])
         model.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/drmnet/eval_drmnet.yaml"))["data"]["params"]["predict"])
         imgs, normals, masks = chain_inputs(B, dev)
@@ -640,10 +651,10 @@ def main():
             # HBM traffic is a PMC quantity: it cannot be read from inside this process.  It is IMPORTED from the committed rocprofv3
             # --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/prof_round.sh -> profiles/rNN_pmc_hbm_traffic.json), per
             # launch of the dominant variant -- and only when that profile was taken on the kernel source this build was made from.
-            roofline.update(imported_traffic(split and not mx and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256)))
+            roofline.update(imported_traffic(split and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256), args.precision))
 
     chain_all = None
-    if (world > 1 or dist is not None) and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_secondary:
+    if (world > 1 or dist is not None) and args.workload == "drmnet_step" and args.precision in ("f16x3", "f16mx") and not args.no_secondary:
         chain_all = full_chain_all_ranks(args, model, dev, dist)  # (DRM_BENCH_DIST=1 exercises it with a single rank)
     if rank == 0:
         value = total_units / dt
@@ -661,7 +672,8 @@ def main():
             "dtype": {"fp32": "f32", "f16x3": "f32 via split f16x3 MFMA (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)",
                       "f16": "f16 operands, fp32 accumulate (REDUCED PRECISION, ~1e-3 rel-L2: not the headline configuration)",
                       "f16mx": "f32 via split f16 hi*hi + block-scaled fp8 (e4m3) cross terms on the GroupNorm-fed 3x3 convs, f16x3 elsewhere, fp32 accumulate "
-                               "(2.4e-5 .. 4e-5 rel-L2 per network against the reference: inside the 1e-4 contract, not the headline configuration)"}[args.precision],
+                               "(2.4e-5 .. 4e-5 rel-L2 per network against the reference, 2e-6 .. 9e-6 on the recorded sampler loops and the full chain: inside the 1e-4 contract; "
+                               "the f16x3 and exact-fp32 figures of the same run are in the f16x3 / strict_fp32 objects of this line)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": args.batch, "refmap": "3x128x128 (from 256x256 object images)" if args.workload == "estimate_chain" else f"3x{args.height}x{args.width}",
                        "weights": "seeded synthetic (no checkpoint offline)", "parallelism": f"batch-sharded x{world}, no collective",
@@ -675,14 +687,19 @@ def main():
             out["full_chain_all_gpus"] = chain_all
         if args.workload == "drmnet_step" and not args.no_parity_check:
             out["parity_check"] = parity_check(model, dev, args.precision)
-        if world == 1 and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_strict_fp32:
+        if world == 1 and args.workload == "drmnet_step" and args.precision in ("f16x3", "f16mx") and not args.no_strict_fp32:
+            if args.precision == "f16mx":  # the three-product split mode (every test at the fp32 tolerances) on the same workload
+                try:
+                    out["f16x3"] = strict_fp32_pass(args, model, dev, L, _lib, "f16x3")
+                except Exception as e:  # noqa: BLE001
+                    out["f16x3"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 out["strict_fp32"] = strict_fp32_pass(args, model, dev, L, _lib)
             except Exception as e:  # noqa: BLE001
                 out["strict_fp32"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and args.workload == "drmnet_step" and args.precision == "f16x3" and not args.no_secondary and (args.batch, args.height, args.width) == (32, 128, 256):
+        if world == 1 and args.workload == "drmnet_step" and args.precision in ("f16x3", "f16mx") and not args.no_secondary and (args.batch, args.height, args.width) == (32, 128, 256):
             try:  # (the headline line must survive a failure of an appended workload)
-                model.set_precision("f16x3")
+                model.set_precision(args.precision)
                 out["secondary"] = secondary_pass(args, model, dev)
             except Exception as e:  # noqa: BLE001
                 out["secondary"] = {"error": f"{type(e).__name__}: {e}"}

@@ -191,7 +191,8 @@ class DRMNet(nn.Module):
         raise NotImplementedError("")  # the reference leaves this unimplemented too (drmnet.py:772-780)
 
     def set_precision(self, precision: str) -> "DRMNet":
-        """Conv arithmetic of both networks: "fp32" (exact fp32 MFMA) or "f16x3" (split fp16, fp32-accurate, ~3x faster)."""
+        """Conv arithmetic of both networks: "fp32" (exact fp32 MFMA), "f16x3" (split fp16, fp32-accurate, ~2.5x faster), "f16mx" (f16x3 with
+        fp8 cross terms on the 3x3 convs: ~3e-5 per network, ~3x faster) or "f16" (reduced precision)."""
         self.illnet_model.diffusion_model.set_precision(precision)
         self.refnet_model.diffusion_model.set_precision(precision)
         return self

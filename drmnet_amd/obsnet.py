@@ -167,7 +167,8 @@ class LatentDiffusion(DDPM):
         self._ws = _lib.Workspace()
 
     def set_precision(self, precision: str):
-        """Conv arithmetic of the U-Net: "fp32" (exact fp32 MFMA) or "f16x3" (split fp16, fp32-accurate, ~3x faster)."""
+        """Conv arithmetic of the U-Net: "fp32" (exact fp32 MFMA), "f16x3" (split fp16, fp32-accurate, ~2.5x faster), "f16mx" (f16x3 with
+        fp8 cross terms on the 3x3 convs: ~4e-5 per forward, ~3x faster) or "f16" (reduced precision)."""
         self.model.diffusion_model.set_precision(precision)
         return self
 

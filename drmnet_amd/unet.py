@@ -142,7 +142,10 @@ class _HipUNetBase(nn.Module):
     def set_precision(self, precision: str) -> "._HipUNetBase":
         """"fp32": exact fp32 products on v_mfma_f32_32x32x2_f32 (default).
         "f16x3": fp32 operands split into fp16 hi+lo, 3 MFMAs per product, fp32 accumulation (fp32-level accuracy,
-        16/3 x the fp32 matrix rate).  Weights are re-packed on the next forward."""
+        16/3 x the fp32 matrix rate).
+        "f16mx": f16x3 with the GroupNorm-fed 3x3 convs on fp16 hi*hi + one block-scaled fp8 MFMA for both cross terms (2/3 of the matrix-pipe
+        cycles; 2.4e-5 .. 4e-5 rel-L2 per network against the reference: inside the 1e-4 contract, tests/test_gpu_f16mx.py).
+        "f16": REDUCED precision (fp16 operands, ~1e-3).  Weights are re-packed on the next forward."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {list(self.PRECISIONS)}")
         _lib.check(_lib.lib().drm_unet_set_precision(self._h, self.PRECISIONS[precision]))

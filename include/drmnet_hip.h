@@ -83,6 +83,12 @@ int drm_unet_use_set(drm_unet* net, int set);
  *       f16 MFMA per product, fp32 accumulation, fp32 activations in HBM.  ~1e-3 rel-L2 on the full networks -- outside the
  *       1e-4 contract of the two modes above; offered for BASELINE configs[2] (the reference's reduced-precision sampling). */
 #define DRM_PREC_F16 2
+/*   3 = DRM_PREC_F16MX: DRM_PREC_F16X3 with the GroupNorm-fed 3x3 convs of the res blocks (80 % of a step's matrix work) evaluated as
+ *       hi*hi on the f16 matrix cores + BOTH cross terms (hi*lo + lo*hi) in one block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, OCP
+ *       e4m3 operands with power-of-two block factors): 2/3 of the matrix-pipe cycles of F16X3.  The cross terms are 2^-11 of a product and
+ *       carry an e4m3 rounding: 7e-6 rel-L2 per res block, 2.4e-5 .. 4e-5 per network against the reference -- inside the 1e-4 contract
+ *       (tests/test_gpu_f16mx.py), an order of magnitude above F16X3's ~2e-6.  Every other launch runs exactly as in F16X3. */
+#define DRM_PREC_F16MX 3
 int drm_unet_set_precision(drm_unet* net, int precision);
 int drm_set_op_precision(int precision);
 

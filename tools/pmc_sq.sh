@@ -4,7 +4,7 @@
 # in their own passes with --kernel-trace only (no --stats / sys-trace), as the GPU pool requires.
 #   usage (on the GPU box): tools/pmc_sq.sh <tag>   -> gpurun_out/pmc_sq/<tag>_pmc_sq_conv.json   (copy it into profiles/)
 tag=${1:-r02}
-PREC=${2:-f16x3}   # f16x3 (conv_split2_kernel<9,...>) or fp32 (conv_igemm_kernel<9,...>)
+PREC=${2:-f16x3}   # f16x3 / f16mx / f16 / fp32 (every mode runs conv_split2_kernel<9,...> on these shapes)
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/pmc_sq"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -18,7 +18,7 @@ python3 - "$tag" "$PREC" <<'PY'
 import collections, glob, hashlib, json, sqlite3, sys
 tag = sys.argv[1]
 prec = sys.argv[2]
-KERN = 'conv_igemm_kernel<9' if prec == 'fp32' else 'conv_split2_kernel<9'
+KERN = 'conv_split2_kernel<9'
 OUT = 'gpurun_out/pmc_sq'
 def rows(sub):
     dbs = sorted(glob.glob(f'{OUT}/{sub}/**/*_results.db', recursive=True))
@@ -26,7 +26,7 @@ def rows(sub):
         return []
     con = sqlite3.connect(dbs[-1])
     return con.execute("select dispatch_id, kernel_name, grid_size, counter_name, value, duration from counters_collection").fetchall()
-res = {"command": "tools/pmc_sq.sh (rocprofv3 --pmc <SQ/GRBM counters> --kernel-trace -- python3 tools/layer_probe.py f16x3; two passes)",
+res = {"command": "tools/pmc_sq.sh (rocprofv3 --pmc <SQ/GRBM counters> --kernel-trace -- python3 tools/layer_probe.py " + prec + "; two passes)",
        "conv_split2_sha16": hashlib.sha256(open('drmnet_amd/csrc/conv_split2.hip', 'rb').read()).hexdigest()[:16],
        "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; "
                 "clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
@@ -72,7 +72,7 @@ for sub in ("p1", "p2"):
         for k, v in avg.items():
             if k not in ("duration_ns",):
                 e.setdefault("raw", {})[k] = round(v, 1)
-json.dump(res, open(f'{OUT}/{tag}_pmc_sq_conv{"_fp32" if prec == "fp32" else ""}.json', 'w'), indent=1)
+json.dump(res, open(f'{OUT}/{tag}_pmc_sq_conv{"" if prec == "f16x3" else "_" + prec}.json', 'w'), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
 rm -rf "$OUT/p1" "$OUT/p2"
