@@ -37,10 +37,10 @@ CASES = [  # (kind, batch, cin, cout, h, w): persistent wide tiles, 192-wide til
 ]
 
 bad = 0
-for precision in ("f16x3", "fp32", "f16"):
+for precision in ("f16mx", "f16x3", "fp32", "f16"):
     ops.set_precision(precision)
     for kind, n, cin, cout, h, w in CASES:
-        if precision != "f16x3" and n == 32 and h >= 128:
+        if precision not in ("f16mx", "f16x3") and n == 32 and h >= 128:
             continue  # (the big shapes once, in the headline mode)
         g = torch.Generator().manual_seed(h * 1000 + w + cin)
         x = torch.randn((n, cin, h, w), generator=g).to(dev)
