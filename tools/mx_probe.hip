@@ -55,7 +55,9 @@ __global__ __launch_bounds__(512) void k_rate(float* out, int iters) {
       } else {          // hybrid: 2 f16 MFMAs + 1 MX fp8 K=64
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i], 0, 0, 0, 115, 0, 127);
+        if (MODE == 1) acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i], 0, 0, 0, 115, 0, 127);
+        if (MODE == 2) acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i], 2, 2, 0, 115, 0, 127);  // fp6 e2m3 operands
+        if (MODE == 3) acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i], 4, 4, 0, 115, 0, 127);  // fp4 e2m1 operands
       }
     }
   }
@@ -99,13 +101,16 @@ int main() {
   // ---- rate
   float* out; hipMalloc(&out, 256 * 512 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode = 0; mode < 2; ++mode) for (int rep = 0; rep < 3; ++rep) {
+  for (int mode = 0; mode < 4; ++mode) for (int rep = 0; rep < 3; ++rep) {
     const int iters = 20000;
     hipEventRecord(e0);
-    if (mode == 0) hipLaunchKernelGGL(k_rate<0>, dim3(256), dim3(512), 0, 0, out, iters); else hipLaunchKernelGGL(k_rate<1>, dim3(256), dim3(512), 0, 0, out, iters);
+    if (mode == 0) hipLaunchKernelGGL(k_rate<0>, dim3(256), dim3(512), 0, 0, out, iters);
+    if (mode == 1) hipLaunchKernelGGL(k_rate<1>, dim3(256), dim3(512), 0, 0, out, iters);
+    if (mode == 2) hipLaunchKernelGGL(k_rate<2>, dim3(256), dim3(512), 0, 0, out, iters);
+    if (mode == 3) hipLaunchKernelGGL(k_rate<3>, dim3(256), dim3(512), 0, 0, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
     const double chunks = 256.0 * 8 * iters * 4;  // (wave, 32x32 block, 32-channel chunk) units
-    printf("mode %d (%s): %.3f ms, %.2f G chunk-blocks/s  -> algorithmic %.0f TFLOP/s\n", mode, mode ? "2 f16 + 1 MX-fp8 K=64" : "6 f16 (f16x3)", ms, chunks / ms * 1e-6, chunks * 2.0 * 32 * 32 * 32 / (ms * 1e-3) / 1e12);
+    printf("mode %d (%s): %.3f ms, %.2f G chunk-blocks/s  -> algorithmic %.0f TFLOP/s\n", mode, mode == 0 ? "6 f16 (f16x3)" : mode == 1 ? "2 f16 + 1 MX-fp8 K=64" : mode == 2 ? "2 f16 + 1 MX-fp6 K=64" : "2 f16 + 1 MX-fp4 K=64", ms, chunks / ms * 1e-6, chunks * 2.0 * 32 * 32 * 32 / (ms * 1e-3) / 1e12);
   }
   return 0;
 }
