@@ -79,8 +79,8 @@ struct ConvArgs {
   int cin_real = 0;                 // un-padded Cin for FLOP accounting (0 = C0 + C1)
   int ksplit = 1;                      // split-K factor (conv_split_ksplit); > 1: split k writes its raw partial sums to out + k * split_stride
   size_t split_stride = 0;             // floats between the split-K slabs (0 unless ksplit > 1)
-  double2* stat_part = nullptr;        // split-K reduction with statistics: [N][splitk_reduce_blocks][Cout] per-block sums ...
-  unsigned* stat_ticket = nullptr;     // ... and [N] arrival counters (zero before the launch): the last block of an image folds its partials
+  float* split_ws = nullptr;           // fused split-K: slab workspace ([ksplit] slabs of split_stride floats); the workgroup that arrives LAST at an output tile
+  unsigned* tile_ticket = nullptr;     // (arrival counter per output tile, zero before the launch) sums the slabs in slab order and runs the full epilogue into `out`
   int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 2 = fp16 hi*hi + fp8 cross terms, 1 = plain fp16 operands
   int mx_site = 0;                     // PREC_F16MX: this launch is one of the 3x3 convs whose weights carry the f16mx image
 #ifdef DRM_S2_STAMP
@@ -101,8 +101,8 @@ int conv_tile_family(int H, int W, const int (*fam)[2], int n_fam);
 // split-precision (fp16 hi/lo x 3 MFMA, fp32-accurate) variant; a.w = pre-split weights (conv_split.hip)
 int launch_conv_split(const ConvArgs& a, hipStream_t s);
 int conv_split_ksplit(const ConvArgs& a);  // split-K factor the split kernels want for this launch (1 = none)
-int splitk_reduce_blocks(int N, int H, int W);  // pixel blocks per image of the reduction that follows a split-K launch
-// deterministic second half of a split-K conv: out = sum of the slabs at `partial` (+ bias, emb, residual), statistics into a.stat_out
+bool conv_split_fused_finish(const ConvArgs& a);  // a split-K launch of this shape finishes its tiles itself (ConvArgs::split_ws / tile_ticket); else launch_splitk_reduce follows
+// deterministic second half of a split-K conv on maps of at most 256 pixels: out = sum of the slabs at `partial` (+ bias, emb, residual), statistics into a.stat_out
 int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s);
 bool conv_split_fuses_stats();  // true when the active split kernel accumulates ConvArgs::stat_out in its epilogue
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);

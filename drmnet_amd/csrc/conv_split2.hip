@@ -222,7 +222,9 @@ struct TilePos {
 
 // RAG: the map is not a whole number of tiles: edge tiles are masked (loads are bounds-checked in every build; the ragged build also
 // masks the epilogue's stores, residual reads and statistics per pixel).  A separate instantiation, so the shipped shapes' code is untouched.
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false>
+// SK: the instantiation split-K launches use (128-row x 32-channel tiles only): it carries the fused finish of the tile -- a separate
+// instantiation because its slab loads cost the narrow kernels 45 registers and one of their three waves per SIMD.
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false, bool SK = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
   extern __shared__ float4 lds[];
@@ -281,7 +283,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   const int chunk0 = split * nch_all / ks;
   const int nchunks = (split + 1) * nch_all / ks - chunk0;  // chunks of THIS workgroup (indices below are local)
   const int NGT = nchunks * C::NG;  // weight groups (pipeline steps) per tile
-  float* const out_s = a.out + (size_t)split * a.split_stride;  // split-K: this split's partial slab (split_stride = 0 otherwise)
+  // split-K: this split's partial slab.  Fused form (a.split_ws): the slabs live in their own workspace and a.out is the real output; two-launch
+  // form: a.out is the workspace and splitk_reduce_kernel follows.
+  constexpr bool FUSE = SK;
+  static_assert(!SK || (WM == 4 && WN == 1 && MT == 1 && NT == 1 && !RAG), "split-K launches use the 128-row x 32-channel tiles (conv_split_ksplit)");
+  const bool fused = FUSE && ks > 1 && a.split_ws != nullptr;
+  float* const out_s = (fused ? a.split_ws : a.out) + (size_t)split * a.split_stride;  // (split_stride = 0 without split-K)
   const bool has_gn = a.gn_scale != nullptr;
 
   // ---- activation loader (ordinary loads, always issued: addresses are clamped, invalid slots zeroed at store time)
@@ -801,6 +808,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
     }
 
     S2_STAMP(9);  // epilogue start
+    [[maybe_unused]] bool fused_last = false;  // fused split-K: this workgroup arrived last at its tile and ran the full epilogue
 #ifdef DRM_S2_STAMP
     // timing experiments of the diagnostic build (tools/epi_cost.sh): stamp_block bit 16 = no output stores, bit 17 = no epilogue at all
     const bool skip_epilogue = a.stamp_block & 0x20000;
@@ -964,7 +972,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           }
         }
         S2_STAMP(22 + 4 * (i * NT + c));  // stores issued
-        if (st) {
+        if (st && first) {
           const int row0 = (wm * MT + i) * 32;
           if (PPI >= 32) {
             s0 += s1;
@@ -981,11 +989,95 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         }
         S2_STAMP(23 + 4 * (i * NT + c));  // statistics atomics issued
       }
+      if constexpr (FUSE) {
+        // Fused split-K finish: hand this split's slab over (every storing wave drains its stores, the workgroup meets, ONE lane releases at
+        // agent scope and draws the tile's ticket -- cdna_hip_programming.md Guideline 16); the workgroup that arrives LAST acquires, sums the
+        // ks slabs of its tile IN SLAB ORDER (its own included: the result does not depend on who was last) and runs the full epilogue --
+        // bias, emb, residual, output statistics -- into the real output.  No second launch, no per-block statistics table.
+        if (fused) {
+          __shared__ int s_last_tile;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool last = __hip_atomic_fetch_add(a.tile_ticket + (x_start + k_tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ks - 1;
+            if (last) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            s_last_tile = last;
+          }
+          __syncthreads();
+          if (s_last_tile) {
+            const int col = wn * 32 + r, co = cur.co0 + col;
+            const int cq = cur.co0 + wn * 32 + (r & ~3);
+            float v[16];
+            // (bias / emb / residual requested first: their latency rides under the slab loads)
+            const float bias = a.bias ? a.bias[co] : 0.f;
+            float rv[16], ev[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ev[g] = a.emb ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rv[e] = a.res ? a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co] : 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < 4; g2 += 2) {  // two row groups at a time: 2 x ks float4 loads in flight
+              float4 t[2][8];
+#pragma unroll
+              for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                  if (k < ks) t[gg][k] = *reinterpret_cast<const float4*>(&a.split_ws[(size_t)k * a.split_stride + (pixb[g2 + gg] + (r & 3)) * a.Cout + cq]);
+#pragma unroll
+              for (int gg = 0; gg < 2; ++gg) {
+                float4 sacc = t[gg][0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k)
+                  if (k < ks) { sacc.x += t[gg][k].x; sacc.y += t[gg][k].y; sacc.z += t[gg][k].z; sacc.w += t[gg][k].w; }
+                const int g = g2 + gg;
+                v[4 * g] = sacc.x; v[4 * g + 1] = sacc.y; v[4 * g + 2] = sacc.z; v[4 * g + 3] = sacc.w;
+                quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], r);  // back to the accumulator layout: one channel, four pixels
+              }
+            }
+            float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int g = e >> 2;
+              const float x = v[e] + bias + ev[g] + rv[e];  // (the order of the one-launch epilogue)
+              v[e] = x;
+              if (okg[g]) {
+                if (e < 8) { s0 += x; q0 += x * x; } else { s1 += x; q1 += x * x; }
+              }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], r);
+              if (okg[g]) *reinterpret_cast<float4*>(&a.out[(pixb[g] + (r & 3)) * a.Cout + cq]) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            }
+            if (st) {  // LDS fold like every full epilogue; the global fold below runs for this workgroup
+              const int row0 = wm * 32;
+              if (PPI >= 32) {
+                s0 += s1;
+                q0 += q1;
+              }
+              double* d = lst + ((size_t)(row0 / PPI) * C::BN + col) * 2;
+              atomicAdd(d, (double)s0);
+              atomicAdd(d + 1, (double)q0);
+              if (PPI < 32) {
+                double* d2 = lst + ((size_t)((row0 + 16) / PPI) * C::BN + col) * 2;
+                atomicAdd(d2, (double)s1);
+                atomicAdd(d2 + 1, (double)q1);
+              }
+            }
+            fused_last = true;
+          }
+        }
+      }
     }
     // The LDS statistics keep accumulating while the workgroup's next tile covers the same images and output channels (on the big maps a
     // workgroup visits several tiles of one image in a row): the fold -- two barriers and TN * BN * 2 global fp64 atomics -- runs only
     // when that changes, not once per tile.
-    if (st && (!has_next || nxt.n0 != cur.n0 || nxt.co0 != cur.co0)) {
+    if (st && (ks == 1 || fused_last) && (!has_next || nxt.n0 != cur.n0 || nxt.co0 != cur.co0)) {
       // fold of the accumulated statistics: LDS -> one global fp64 atomic per (image, channel, moment); re-zero for the next tile
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -1018,10 +1110,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #endif
 }
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false, bool SK = false>
 static int launch_s2(const ConvArgs& a, hipStream_t s) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
-  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS, RAG>;
+  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS, RAG, SK>;
   DRM_REQUIRE(RAG || (a.H % TH == 0 && a.W % TW == 0), "conv tile does not divide the map");
   const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
   static_assert(C::LDS_F4 * 16 <= 160 * 1024, "LDS budget");
@@ -1042,7 +1134,10 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
   long long grid = (long long)di->cus * per_cu;
   const int ngt = ((a.C0 + a.C1) / C::KC) * C::NG;  // weight groups per tile
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  DRM_REQUIRE(ks == 1 || (!a.out_nchw && !a.stat_out && a.split_stride > 0 && a.w_img_stride_f4 == 0 && ((a.C0 + a.C1) / C::KC) / ks >= 1), "split-K launch contract");
+  constexpr bool FUSE = SK;
+  DRM_REQUIRE(ks == 1 || (!a.out_nchw && a.split_stride > 0 && a.w_img_stride_f4 == 0 && ((a.C0 + a.C1) / C::KC) / ks >= 1 && ks <= 8 &&
+                          (a.split_ws ? (FUSE && a.tile_ticket != nullptr) : !a.stat_out)),
+              "split-K launch contract");
   if (tiles < grid || ngt < R - 1 || (TAPS == 1 && ngt < 2) || ks > 1) grid = tiles;  // (a prefetch may only reach into the NEXT tile)
   {
     const double cin = a.cin_real > 0 ? a.cin_real : (a.C0 + a.C1), cout = a.out_nchw ? a.cout_valid : a.Cout;
@@ -1130,6 +1225,7 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
   }
   if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
+  if (a.ksplit > 1 && a.split_ws) return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS, TERMS, false, true>(a, s);  // (conv_split_ksplit: only ever here)
   return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS, TERMS>(a, s);
 }
 
@@ -1166,9 +1262,14 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
   }
 }
 
+// Who finishes a split-K conv.  Maps of at least 128 pixels: the launch itself -- the workgroup that arrives last at an output tile sums the slabs in
+// slab order and runs the full epilogue (SK instantiation; the hand-off costs ~10 us whatever the shape).  Smaller maps: splitk_reduce_small_kernel
+// in a second launch (5.8 us on the 4x8 maps of the batch-32 step, where the fused finish measured 1 % slower on the whole step; at batch 1 the maps
+// of 128 .. 1024 pixels are where the second launch cost 12 .. 22 us: 6.64 -> 6.0 ms per step with the fused finish).
+bool conv_split_fused_finish(const ConvArgs& a) { return a.H * a.W >= 128; }
+
 // Split-K factor for a launch (1 = none).  Mirrors dispatch_s2_bn: only the 128-row x 32-channel fallback tiles qualify, when
-// their grid leaves most of the 256 CUs idle and the reduction is long; the caller zero-fills nothing (the launcher does) but
-// must not ask for fused output statistics (partial sums have no statistics) -- engine.hip:run_conv checks this first.
+// their grid leaves most of the 256 CUs idle and the reduction is long.
 int conv_split_ksplit(const ConvArgs& a) {
   if (a.out_nchw || !s2_exact(a) || a.w_img_stride_f4 != 0) return 1;
   // (1x1 convs too [r3]: on the deep, small maps a K = 768 .. 1536 reduction is 24 .. 48 serial one-chunk steps of a handful of workgroups --
@@ -1184,120 +1285,11 @@ int conv_split_ksplit(const ConvArgs& a) {
   return (int)std::max<long long>(ks, 1);
 }
 
-// Fixed-order sum of the split-K slabs (already un-scaled by their launch) + everything the conv epilogue would have added: out = sum_k partial[k] + bias
-// (+ emb[n] + residual), and the per-(image, channel) sums / sums of squares of the result for the next GroupNorm.  The slab
-// order is fixed, so the result does not depend on which workgroup finished first (the atomic accumulation it replaces did).
-// grid (pixel blocks, N), block 256: thread = (channel quad, pixel lane); per-thread fp32 partial statistics, folded per block in LDS,
-// written as one fp64 pair per (block, channel) to stat_part; the LAST block of an image to arrive (ticket counter) adds the blocks'
-// pairs in block order and stores the table.  No atomics on the statistics either: every block of an image used to end in
-// same-address fp64 atomics, which serialise at ~0.6 us each at the memory side (38 us per launch at batch 1, 68 launches per step).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ partial, size_t slab_f4, int ks, const float* __restrict__ bias,
-                                                            const float* __restrict__ emb, int emb_stride, const float* res /* may alias out: skip_connection blocks */,
-                                                            float4* out, double2* __restrict__ stat, double2* __restrict__ stat_part,
-                                                            unsigned* __restrict__ ticket, int HW, int Cout, int px_per_block) {
-  __shared__ float red[256][8];
-  __shared__ bool s_last;
-  const int n = blockIdx.y, q4 = Cout >> 2;
-  const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, HW);
-  const int ql = threadIdx.x % 64, pl = threadIdx.x / 64;
-  for (int q0 = 0; q0 < q4; q0 += 64) {  // 64 channel quads x 4 pixel lanes per pass (every thread runs every pass: barriers below)
-    const int q = q0 + ql;
-    if (q >= q4 && !stat) continue;
-    float4 b = (bias && q < q4) ? reinterpret_cast<const float4*>(bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (emb && q < q4) {
-      const float4 e = *reinterpret_cast<const float4*>(emb + (size_t)n * emb_stride + 4 * q);
-      b.x += e.x; b.y += e.y; b.z += e.z; b.w += e.w;
-    }
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4  // (independent pixels: lets the loads of four iterations be in flight together -- the loop is latency-bound)
-    for (int p = p0 + pl; p < p1 && q < q4; p += 4) {
-      const size_t idx = ((size_t)n * HW + p) * q4 + q;
-      float4 acc = partial[idx];
-      for (int k = 1; k < ks; ++k) {
-        const float4 t = partial[idx + (size_t)k * slab_f4];
-        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-      }
-      float4 v = make_float4(acc.x + b.x, acc.y + b.y, acc.z + b.z, acc.w + b.w);
-      if (res) {
-        const float4 r = reinterpret_cast<const float4*>(res)[idx];
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-      }
-      out[idx] = v;
-      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-      ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
-    }
-    if (stat) {  // fold the 4 pixel lanes of a channel quad in LDS (fixed order), then one fp64 atomic per (block, channel, moment)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        red[threadIdx.x][k] = s[k];
-        red[threadIdx.x][4 + k] = ss[k];
-      }
-      __syncthreads();
-      if (pl == 0 && q < q4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          double a = 0.0, c2 = 0.0;
-          for (int j = 0; j < 4; ++j) {
-            a += (double)red[j * 64 + ql][k];
-            c2 += (double)red[j * 64 + ql][4 + k];
-          }
-          if (gridDim.x == 1) {  // the image's only block: its sums ARE the table
-            double2* d = stat + (size_t)n * Cout + 4 * q + k;
-            *d = make_double2(d->x + a, d->y + c2);
-          } else {
-            stat_part[((size_t)n * gridDim.x + blockIdx.x) * Cout + 4 * q + k] = make_double2(a, c2);
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (stat && gridDim.x > 1) {
-    // hand-off of this block's pairs (cdna_hip_programming.md Guideline 16): every storing wave drains its stores, the workgroup meets, ONE
-    // lane releases at agent scope and draws the ticket; the last arriver acquires once before the plain loads of its fold
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      s_last = __hip_atomic_fetch_add(ticket + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-      if (s_last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-    __syncthreads();
-    if (s_last) {
-      for (int c = threadIdx.x; c < Cout; c += 256) {
-        double a = 0.0, c2 = 0.0;
-        const double2* sp = stat_part + (size_t)n * gridDim.x * Cout + c;
-        unsigned b = 0;
-        for (; b + 8 <= gridDim.x; b += 8) {  // eight independent loads in flight, added in block order
-          double2 t[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) t[j] = sp[(size_t)(b + j) * Cout];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            a += t[j].x;
-            c2 += t[j].y;
-          }
-        }
-        for (; b < gridDim.x; ++b) {
-          const double2 t = sp[(size_t)b * Cout];
-          a += t.x;
-          c2 += t.y;
-        }
-        double2* d = stat + (size_t)n * Cout + c;
-        *d = make_double2(d->x + a, d->y + c2);
-      }
-    }
-  }
-}
-
-// Small maps (H * W <= 256: the deep levels, every level at batch 1): the same fixed-order reduction with the whole image in ONE block per 16
-// channel quads -- 16 quads x 16 pixel lanes, so a lane walks at most 16 pixels with its slab loads in flight together, the lanes of a channel
-// fold in LDS in lane order and the block's sums ARE the statistics: no partial table, no ticket, no fence.  (The general kernel below spent most
-// of its 17-22 us per launch at batch 1 in serial passes over the channel quads and in the last-arriver hand-off.)
+// Second launch of a split-K conv on the smallest maps (H * W < 128: conv_split_fused_finish says which): out = sum of the slabs in slab order (already
+// un-scaled by their launch) + bias (+ emb[n] + residual), and the per-(image, channel) sums / sums of squares of the result for the next GroupNorm.
+// The whole image sits in ONE block per 16 channel quads -- 16 quads x 16 pixel lanes, the lanes of a channel fold in LDS in lane order and the
+// block's sums ARE the statistics: no partial table, no ticket, no fence, no atomics; 5.8 us at batch 32 on the 4x8 maps.  Larger maps finish inside
+// the conv launch (conv_split2_kernel<..., SK>): there this kernel took 12 us (22 us beyond 256 pixels, in a second kernel with a ticket hand-off).
 __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float4* __restrict__ partial, size_t slab_f4, int ks, const float* __restrict__ bias,
                                                                   const float* __restrict__ emb, int emb_stride, const float* res /* may alias out */,
                                                                   float4* out, double2* __restrict__ stat, int HW, int Cout) {
@@ -1353,34 +1345,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float4* 
   }
 }
 
-// pixels per block of the reduction (a multiple of the 4 pixel lanes): about 128 blocks over the whole batch -- the loop is latency-bound,
-// the last block's fold grows with the blocks per image
-static int splitk_reduce_ppb(int N, int HW) {
-  // (at most 32 blocks per image: the last arriver folds the blocks' pairs serially, eight loads in flight -- 128 blocks at batch 1 made that
-  //  fold 16 dependent round trips, most of the launch's 22 us)
-  int want = std::max(1, std::min(std::min(HW / 4, 32), (128 + N - 1) / N));  // blocks per image
-  if (want <= 4) want = 1;  // a batch that fills the chip by itself: one block per image, nothing to fold
-  return std::max(4, ((HW + want - 1) / want + 3) & ~3);
-}
-int splitk_reduce_blocks(int N, int H, int W) {
-  const int HW = H * W, ppb = splitk_reduce_ppb(N, HW);
-  return (HW + ppb - 1) / ppb;
-}
-
 int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s) {
-  DRM_REQUIRE(a.ksplit > 1 && a.split_stride % 4 == 0 && a.Cout % 4 == 0, "split-K reduction arguments");
   const int HW = a.H * a.W;
-  if (HW <= 256) {
-    hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((a.Cout / 4 + 15) / 16, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),
-                       a.split_stride / 4, a.ksplit, a.bias, a.emb, a.emb_stride, a.res, reinterpret_cast<float4*>(a.out), a.stat_out, HW, a.Cout);
-    DRM_HIP_CHECK(hipGetLastError());
-    return DRM_OK;
-  }
-  const int ppb = splitk_reduce_ppb(a.N, HW);
-  DRM_REQUIRE(!a.stat_out || (a.stat_part && a.stat_ticket), "split-K reduction with statistics needs its partial table and ticket counters");
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((HW + ppb - 1) / ppb, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),
-                     a.split_stride / 4, a.ksplit, a.bias, a.emb, a.emb_stride, a.res, reinterpret_cast<float4*>(a.out),
-                     a.stat_out, a.stat_part, a.stat_ticket, HW, a.Cout, ppb);
+  DRM_REQUIRE(a.ksplit > 1 && a.split_stride % 4 == 0 && a.Cout % 4 == 0 && HW <= 256, "split-K reduction arguments (maps of more than 256 pixels finish inside the conv launch)");
+  hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((a.Cout / 4 + 15) / 16, a.N), dim3(256), 0, s, reinterpret_cast<const float4*>(partial),
+                     a.split_stride / 4, a.ksplit, a.bias, a.emb, a.emb_stride, a.res, reinterpret_cast<float4*>(a.out), a.stat_out, HW, a.Cout);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }

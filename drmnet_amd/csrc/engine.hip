@@ -302,11 +302,16 @@ float* plan_splitk(Ctx& c, ConvArgs& a) {
   a.ksplit = conv_split_ksplit(a);
   if (a.ksplit <= 1) return nullptr;
   a.split_stride = (size_t)a.N * a.H * a.W * a.Cout;
-  // the reduction's per-block statistics pairs and per-image arrival counters (zeroed: from the pass's statistics pool, else here)
-  a.stat_part = c.ar->alloc<double2>((size_t)a.N * splitk_reduce_blocks(a.N, a.H, a.W) * a.Cout);
-  bool zeroed = false;
-  a.stat_ticket = reinterpret_cast<unsigned*>(c.ar->alloc_stats((size_t)a.N * sizeof(unsigned), &zeroed));
-  if (!zeroed && !c.dry()) (void)hipMemsetAsync(a.stat_ticket, 0, (size_t)a.N * sizeof(unsigned), c.s);
+  a.tile_ticket = nullptr;
+  if (conv_split_fused_finish(a)) {
+    // one arrival counter per output tile (128 GEMM rows x 32 channels; an upper bound over the pixel-tile families), zeroed: from the pass's
+    // statistics pool, else here -- the workgroup that arrives last at a tile sums the slabs and runs the full epilogue (conv_split2.hip)
+    const size_t hw = (size_t)a.H * a.W;
+    const size_t tickets = ((size_t)a.N * hw / 128 + hw / 16 + 2) * (size_t)(a.Cout / 32);
+    bool zeroed = false;
+    a.tile_ticket = reinterpret_cast<unsigned*>(c.ar->alloc_stats(tickets * sizeof(unsigned), &zeroed));
+    if (!zeroed && !c.dry()) (void)hipMemsetAsync(a.tile_ticket, 0, tickets * sizeof(unsigned), c.s);
+  }
   return c.ar->alloc<float>(a.split_stride * a.ksplit);
 }
 
@@ -325,9 +330,8 @@ int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_
       stats_for->mom_valid = true;
       stats_for->mom_sums = true;
     }
-    if (a.ksplit > 1) {
-      // deep levels: the reduction is split over workgroups; every split writes its own slab, a fixed-order pass sums them and
-      // applies bias / emb / residual / statistics (deterministic: no atomics on the data path)
+    if (a.ksplit > 1 && !a.tile_ticket) {
+      // smallest maps: every split writes its own slab, a fixed-order second launch sums them and applies bias / emb / residual / statistics
       ConvArgs part = a;
       part.out = splitk_ws;
       part.bias = nullptr; part.emb = nullptr; part.res = nullptr; part.stat_out = nullptr;
@@ -336,6 +340,9 @@ int run_conv(Ctx& c, ConvArgs& a, const float* Wb, size_t scale_off, Act* stats_
       red.stat_out = stat;
       return launch_splitk_reduce(red, splitk_ws, c.s);
     }
+    // (other split-K launches: the workgroup that arrives last at an output tile sums the slabs in slab order and applies bias / emb /
+    //  residual / statistics itself -- one launch, no atomics on the data path)
+    a.split_ws = a.ksplit > 1 ? splitk_ws : nullptr;
     a.stat_out = stat;
     return launch_conv_split(a, c.s);
   }
