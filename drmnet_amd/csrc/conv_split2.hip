@@ -17,6 +17,9 @@
 //     one global fp64 atomic per (image, channel, moment) per tile).
 // All vector-memory operations a wave issues are unconditional (clamped addresses, zero-filled afterwards) so the
 // vmcnt bookkeeping below is exact and identical for every wave.
+// Arithmetic (TERMS): 3 = the three-product fp16 split above; 2 = hi*hi on the f16 MFMA + both cross terms in one block-scaled fp8 MFMA
+// ("f16mx", the GroupNorm-fed 3x3 convs); 1 = plain fp16 operands; 0 = exact fp32 (v_mfma_f32_32x32x2_f32) -- all on this one pipeline.
+// Split-K (deep, small maps): every split writes its own slab; SK instantiations finish the tile inside the launch (last-arriving workgroup).
 #include <algorithm>
 #include <atomic>
 #include <utility>
