@@ -14,6 +14,13 @@ drawn from one CPU ``torch.Generator`` per network, consumed in
 
 torch's CPU generator is deterministic for a fixed torch version, so the GPU
 box regenerates bit-identical tensors from (ordered keys, shapes, seed).
+
+``rule="stress"`` is the weight-stress distribution of the f16mx parity tests
+(heavier tails, larger GroupNorm gains):
+
+* ``ndim >= 2``      -> Student-t, 4 degrees of freedom, unit variance, ``/ sqrt(fan_in)``
+* 1-D ``*.weight``   -> ``10 * (1 + 0.1 * randn)``       (GroupNorm gamma x 10)
+* 1-D ``*.bias``     -> ``0.1 * randn``
 """
 from __future__ import annotations
 
@@ -29,25 +36,36 @@ SEED_ZEMB = 4
 SEED_INPUT = 1234
 
 
-def synth_tensor(name: str, shape: Sequence[int], gen: torch.Generator) -> torch.Tensor:
+STRESS_DOF = 4
+STRESS_GAIN = 10.0
+
+
+def synth_tensor(name: str, shape: Sequence[int], gen: torch.Generator, rule: str = "normal") -> torch.Tensor:
     shape = tuple(int(s) for s in shape)
+    if rule not in ("normal", "stress"):
+        raise ValueError(rule)
     if len(shape) >= 2:
         fan_in = 1
         for s in shape[1:]:
             fan_in *= s
-        return torch.randn(shape, generator=gen, dtype=torch.float32) / math.sqrt(fan_in)
+        z = torch.randn(shape, generator=gen, dtype=torch.float32)
+        if rule == "stress":  # t_4 = z / sqrt(chi2_4 / 4), variance 4 / (4 - 2) = 2
+            chi = torch.randn((STRESS_DOF,) + shape, generator=gen, dtype=torch.float32).square().mean(0)
+            z = z / chi.sqrt() / math.sqrt(STRESS_DOF / (STRESS_DOF - 2.0))
+        return z / math.sqrt(fan_in)
     if name.endswith("weight"):
-        return 1.0 + 0.1 * torch.randn(shape, generator=gen, dtype=torch.float32)
+        g = 1.0 + 0.1 * torch.randn(shape, generator=gen, dtype=torch.float32)
+        return g * STRESS_GAIN if rule == "stress" else g
     return 0.1 * torch.randn(shape, generator=gen, dtype=torch.float32)
 
 
-def synth_state_dict(manifest: Iterable[Tuple[str, Sequence[int]]], seed: int) -> Dict[str, torch.Tensor]:
+def synth_state_dict(manifest: Iterable[Tuple[str, Sequence[int]]], seed: int, rule: str = "normal") -> Dict[str, torch.Tensor]:
     """manifest: ordered (key, shape) pairs in ``state_dict()`` order."""
     gen = torch.Generator(device="cpu")
     gen.manual_seed(int(seed))
     out: Dict[str, torch.Tensor] = {}
     for name, shape in manifest:
-        out[name] = synth_tensor(name, shape, gen)
+        out[name] = synth_tensor(name, shape, gen, rule)
     return out
 
 
@@ -55,8 +73,8 @@ def manifest_of(module: torch.nn.Module) -> List[Tuple[str, Tuple[int, ...]]]:
     return [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
 
 
-def load_synth(module: torch.nn.Module, seed: int) -> None:
-    sd = synth_state_dict(manifest_of(module), seed)
+def load_synth(module: torch.nn.Module, seed: int, rule: str = "normal") -> None:
+    sd = synth_state_dict(manifest_of(module), seed, rule)
     module.load_state_dict(sd, strict=True)
 
 

@@ -11,6 +11,14 @@ if ROOT not in sys.path:
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
+# Per-mode bars on a single network forward / sampler state against the reference (rel-L2).  fp32 / f16x3 / f16mx are the modes held to the
+# north-star contract (1e-4); f16mx (bench.py's default arithmetic) is asserted at 5e-5 on whole networks, half the contract
+# (VERDICT r03 item 1); f16 and bf16 are the reduced-precision modes of BASELINE configs[2] with their own stated tolerances.
+NET_TOL = {"fp32": 2e-5, "f16x3": 2e-5, "f16mx": 5e-5, "f16": 5e-3, "bf16": 3e-2}
+CONTRACT = 1e-4
+ACCURATE_MODES = ["fp32", "f16x3", "f16mx"]
+SPLIT_MODES = ["f16x3", "f16mx"]
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

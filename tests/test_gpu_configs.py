@@ -14,14 +14,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLD, gold, rel_l2
+from conftest import CONTRACT, GOLD, NET_TOL, gold, rel_l2
 from drmnet_amd import synth
 from oracle import unet as ou
 from test_gpu_nets import build, full_inputs
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(GOLD))
-TOL = {"fp32": 2e-5, "f16x3": 2e-5, "f16": 5e-3}  # f16 is the reduced-precision mode with its own stated tolerance
+TOL = NET_TOL  # per-mode bars (tests/conftest.py): f16mx, bench.py's default arithmetic, at 5e-5; f16 is the reduced-precision mode with its own stated tolerance
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +30,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("B,precision", [(32, "f16x3"), (32, "f16"), (256, "f16x3"), (256, "f16")])
+@pytest.mark.parametrize("B,precision", [(32, "f16x3"), (32, "f16mx"), (32, "f16"), (128, "f16mx"), (256, "f16x3"), (256, "f16mx"), (256, "f16")])
 def test_obsnet_metric_shape_batches(dev, B, precision):
     gd = gold("full_obsnet_128x256")
     m = build(ou.OBSNET_CFG, "unet", int(gd["seed"]), dev).set_precision(precision)
@@ -42,6 +42,7 @@ def test_obsnet_metric_shape_batches(dev, B, precision):
     assert tuple(out.shape) == (B, 3, 128, 256) and torch.isfinite(out).all()
     for r in (0, 2, B // 2, B - 2):
         e = rel_l2(out[r].cpu(), gd["out"][0])
+        print(f"ObsNet B={B} ({precision}) row {r}: {e:.2e}")
         assert e < TOL[precision], (r, e)
     assert rel_l2(out[1].cpu(), out[B - 1].cpu()) < 1e-6
     if B == 32:
@@ -84,7 +85,7 @@ def sampler_inputs(g):
     return cond, x_T, noise
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16mx"])
 def test_full_width_sampler_steps_vs_reference(dev, precision):
     from drmnet_amd.ddim import DDIMSampler
 
@@ -96,7 +97,7 @@ def test_full_width_sampler_steps_vs_reference(dev, precision):
         x, _ = s.sample(50, 1, (3, 128, 256), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, num_steps=k)
         e = rel_l2(x.cpu(), g["ddim_x"][k - 1])
         print(f"full-width ddim ({precision}) after {k} step(s): {e:.2e}")
-        assert e < 1e-5  # observed 1.5e-6
+        assert e < (1e-5 if precision != "f16mx" else CONTRACT)  # observed 1.5e-6 (f16mx: the eps error of one forward, x sqrt(1/abar - 1) at the top of the schedule)
     # ancestral: the device loop walks t = T-1 .. 0 for `start_T` steps from the top only when T == start_T, so the two reference
     # steps (t = 999, 998) are taken through the per-step drop-in p_sample (same fused update kernel)
     img = x_T
@@ -104,21 +105,22 @@ def test_full_width_sampler_steps_vs_reference(dev, precision):
         img, x0 = m.p_sample(img, [cond], torch.full((1,), t, dtype=torch.long, device=dev), clip_denoised=False, return_x0=True, noise=noise[j])
         e = rel_l2(img.cpu(), g["ddpm_x"][j])
         print(f"full-width ddpm ({precision}) t={t}: {e:.2e}")
-        assert e < 2e-6  # observed 2.5e-7
+        assert e < (2e-6 if precision != "f16mx" else 2e-5)  # observed 2.5e-7
         e0 = rel_l2(x0.cpu(), g["ddpm_pred_x0"][j])
         print(f"full-width ddpm ({precision}) t={t}: pred_x0 {e0:.2e}")
-        assert e0 < 1e-5  # observed 1.4e-6 .. 1.7e-6 (x_recon amplifies eps by sqrt(1/abar - 1) at t = 999: both sides alike)
+        assert e0 < (1e-5 if precision != "f16mx" else CONTRACT)  # observed 1.4e-6 .. 1.7e-6 (x_recon amplifies eps by sqrt(1/abar - 1) at t = 999: both sides alike)
     del m
     torch.cuda.empty_cache()
 
 
-def test_batch32_ddim_and_ddpm_device_loop_vs_host_steps(dev):
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_batch32_ddim_and_ddpm_device_loop_vs_host_steps(dev, precision):
     """B = 32 @128x256 on the full-width ObsNet: one DDIM step and a 3-step ancestral run, device loops (drm_ddim_sample /
     drm_ddpm_sample with injected noise) against the same steps driven from the host through the reference-named per-step
     methods (apply_model + the reference's update arithmetic in torch on the device tensors)."""
     from drmnet_amd.ddim import DDIMSampler
 
-    m = full_obsnet(dev, "f16x3")
+    m = full_obsnet(dev, precision)
     B = 32
     gen = torch.Generator().manual_seed(123)
     cond = (synth.synth_refmaps(B, 128, 256, 7) * 2 - 1).to(dev)
@@ -142,7 +144,8 @@ def test_batch32_ddim_and_ddpm_device_loop_vs_host_steps(dev):
     torch.cuda.empty_cache()
 
 
-def test_estimate_batch_equals_replicated_estimate(dev):
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_estimate_batch_equals_replicated_estimate(dev, precision):
     """scripts/estimate.py:29-102 batched: B copies of data/sample through estimate_batch == estimate on one copy, row by row
     (Philox noise keyed by (seed, element): the single-image run is row 0 of the same stream)."""
     from drmnet_amd import file_io
@@ -151,8 +154,8 @@ def test_estimate_batch_equals_replicated_estimate(dev):
 
     g = gold("estimate_chain")
     drm, obs = tiny_models(g, dev)
-    drm.set_precision("f16x3")
-    obs.set_precision("f16x3")
+    drm.set_precision(precision)
+    obs.set_precision(precision)
     d = os.path.join(GOLD, "sample")
     img = file_io.load_exr(os.path.join(d, "image.exr"), as_torch=True).to(dev)
     nrm = torch.from_numpy(np.load(os.path.join(d, "normal.npy"))).to(dev)
@@ -173,4 +176,4 @@ def test_estimate_batch_equals_replicated_estimate(dev):
     # and the whole batch still matches the reference trace at the north-star tolerance
     e_ref = rel_l2(Lr0_b[B - 1].cpu(), g["Lr0"])
     print(f"estimate_batch row vs reference trace: {e_ref:.2e}")
-    assert e_ref < 2e-5  # (observed 4e-6; the north-star bar is 1e-4)
+    assert e_ref < (2e-5 if precision != "f16mx" else CONTRACT)  # (observed 4e-6; the north-star bar is 1e-4)

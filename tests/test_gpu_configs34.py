@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLD, gold, rel_l2
+from conftest import CONTRACT, GOLD, NET_TOL as MODE_TOL, gold, rel_l2
 from drmnet_amd import synth
 from oracle import samplers as osamp
 from oracle import unet as ou
@@ -66,15 +66,18 @@ def shape_heads(m, g):
 
 # --------------------------------------------------------------------------------------------- configs[3]: 256 refmaps per GPU
 
+_STEP_ORACLE = {}
 
-def test_illnet_and_refnet_batch256_vs_reference_golden(dev):
+
+@pytest.mark.parametrize("B,precision", [(256, "f16x3"), (256, "f16mx"), (128, "f16mx")])
+def test_illnet_and_refnet_batch256_vs_reference_golden(dev, B, precision):
+    """B = 256: the per-GPU shard of configs[3]; B = 128: the north-star's batch 1024 over 8 GPUs"""
     xc, t_emb = full_inputs(1, 128, 256)
-    B = 256
     xb = xc.repeat(B, 1, 1, 1).to(dev)
     xb[1::2] = xb[1::2].flip(-1)  # odd rows see a different (valid) input: a row mix-up cannot cancel out
     for name, cfg, kind in (("illnet", ou.ILLNET_CFG, "unet"), ("refnet", ou.REFNET_CFG, "encoder")):
         gd = gold(f"full_{name}_128x256")
-        m = build(cfg, kind, int(gd["seed"]), dev).set_precision("f16x3")
+        m = build(cfg, kind, int(gd["seed"]), dev).set_precision(precision)
         if name == "illnet":
             out = m(xb, t_emb=t_emb.repeat(B, 1).to(dev))
         else:
@@ -82,7 +85,8 @@ def test_illnet_and_refnet_batch256_vs_reference_golden(dev):
         assert out.shape[0] == B and torch.isfinite(out).all()
         for r in (0, 2, B // 2, B - 2):
             e = rel_l2(out[r].cpu(), gd["out"][0])
-            assert e < NET_TOL, (name, r, e)
+            print(f"{name} B={B} ({precision}) row {r}: {e:.2e}")
+            assert e < MODE_TOL[precision], (name, r, e)
         assert rel_l2(out[1].cpu(), out[B - 1].cpu()) < 1e-6
         perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(dev)
         if name == "illnet":
@@ -94,11 +98,12 @@ def test_illnet_and_refnet_batch256_vs_reference_golden(dev):
         torch.cuda.empty_cache()
 
 
-def test_drmnet_step_batch256_vs_oracle_rows(dev):
+@pytest.mark.parametrize("B,precision", [(256, "f16x3"), (256, "f16mx"), (128, "f16mx")])
+def test_drmnet_step_batch256_vs_oracle_rows(dev, B, precision):
     """One whole reverse step (RefNet -> BRDF schedule -> z-MLP -> IllNet -> update, models/drmnet.py:796-839) of 256 refmaps
     @3x128x256: rows 0 / 1 / 254 / 255 against the CPU oracle's step on the same two distinct inputs, K and zk included."""
-    m = full_drmnet(dev, max_timesteps=2, epsilon=0.01, gamma=0.9)
-    B, H, W = 256, 128, 256
+    m = full_drmnet(dev, precision, max_timesteps=2, epsilon=0.01, gamma=0.9)
+    H, W = 128, 256
     base = synth.synth_refmaps(2, H, W, 77)
     LrK = base.repeat(B // 2, 1, 1, 1).to(dev)  # even rows = base[0], odd rows = base[1]
     g = torch.Generator().manual_seed(9)
@@ -115,12 +120,15 @@ def test_drmnet_step_batch256_vs_oracle_rows(dev):
     Pe = synth.synth_state_dict(ou.param_manifest(ou.REFNET_CFG, "encoder"), synth.SEED_REFNET)
     Pz = synth.synth_state_dict(ou.zemb_manifest(6, 128), synth.SEED_ZEMB)
     tu, te = ou.build_topology(ou.ILLNET_CFG, "unet"), ou.build_topology(ou.REFNET_CFG, "encoder")
-    ref = osamp.drmnet_sample(lambda xc, t: ou.encoder_forward(Pe, te, xc, t), lambda xc, dz: ou.unet_forward(Pu, tu, xc, t_emb=ou.z_embed(Pz, dz)),
-                              base, n0, sn, torch.tensor(m._z0.tolist()), 0.9, 0.01, float(m.delta), 2)
+    if "ref" not in _STEP_ORACLE:  # (the same two inputs for every (B, precision): the CPU oracle runs once per session)
+        _STEP_ORACLE["ref"] = osamp.drmnet_sample(lambda xc, t: ou.encoder_forward(Pe, te, xc, t),
+                                                  lambda xc, dz: ou.unet_forward(Pu, tu, xc, t_emb=ou.z_embed(Pz, dz)),
+                                                  base, n0, sn, torch.tensor(m._z0.tolist()), 0.9, 0.01, float(m.delta), 2)
+    ref = _STEP_ORACLE["ref"]
     assert K[:2].tolist() == ref[2].tolist()
     for r in (0, 1, B - 2, B - 1):
         e = rel_l2(Lr0[r].cpu(), ref[0][r % 2])
-        print(f"DRMNet 2 steps, B = 256 @128x256, row {r}: rel-L2 vs oracle {e:.2e}")
+        print(f"DRMNet 2 steps, B = {B} @128x256 ({precision}), row {r}: rel-L2 vs oracle {e:.2e}")
         assert e < 1e-4 and K[r] == ref[2][r % 2]
     assert rel_l2(Lr0[0].cpu(), Lr0[B - 2].cpu()) < 1e-6 and rel_l2(Lr0[1].cpu(), Lr0[B - 1].cpu()) < 1e-6
     zk_last = inter["zk_inter"][-1]
@@ -132,7 +140,7 @@ def test_drmnet_step_batch256_vs_oracle_rows(dev):
 # --------------------------------------------------------------------------------------------- full-width loop vs the reference
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16mx"])
 def test_full_width_p_sample_loop_vs_reference_trace(dev, precision):
     g = gold("drmnet_loop_full")
     T, B = int(g["max_timesteps"]), int(g["B"])
@@ -148,16 +156,17 @@ def test_full_width_p_sample_loop_vs_reference_trace(dev, precision):
     e = rel_l2(Lr0.cpu(), g["Lr0"])
     print(f"full-width DRMNet loop ({precision}): K = {K.tolist()} (reference {g['K'].tolist()}), Lr0 rel-L2 {e:.2e}")
     assert K.tolist() == g["K"].tolist() and sorted(set(K.tolist())) == [2, 3, 5]  # early, mid-loop, never
-    assert e < 2e-5
-    assert np.allclose(zK.cpu().numpy(), g["zK"], atol=1e-5, equal_nan=True) and np.isnan(g["zK"]).any()
+    tol, ztol = (2e-5, 1e-5) if precision != "f16mx" else (MODE_TOL["f16mx"], 1e-4)
+    assert e < tol
+    assert np.allclose(zK.cpu().numpy(), g["zK"], atol=ztol, equal_nan=True) and np.isnan(g["zK"]).any()
     # host-driven loop with intermediates: every logged step of the reference trace
     Lr0h, zKh, Kh, inter = m.p_sample_loop(LrK, [LrK], [LrK], return_intermediates=True, verbose=False, log_every_k=1, noise0=n0, step_noise=sn)
-    assert Kh.tolist() == g["K"].tolist() and rel_l2(Lr0h.cpu(), g["Lr0"]) < 2e-5
+    assert Kh.tolist() == g["K"].tolist() and rel_l2(Lr0h.cpu(), g["Lr0"]) < tol
     steps = torch.stack(inter["Lrk_inter"][1:])[:, :, :, ::4, ::4].cpu()
     assert tuple(steps.shape) == tuple(g["Lrk_steps"].shape)
     for i in range(steps.shape[0]):
-        assert rel_l2(steps[i], g["Lrk_steps"][i]) < 2e-5, i
-        assert np.allclose(inter["zk_inter"][i].cpu().numpy(), g["zk_steps"][i], atol=1e-5, equal_nan=True), i
+        assert rel_l2(steps[i], g["Lrk_steps"][i]) < tol, i
+        assert np.allclose(inter["zk_inter"][i].cpu().numpy(), g["zk_steps"][i], atol=ztol, equal_nan=True), i
     del m
     torch.cuda.empty_cache()
 
@@ -205,7 +214,7 @@ def chain_draws(g, res=128):
     return x_T, noise, noise0, step_noise
 
 
-@pytest.mark.parametrize("precision", ["f16x3"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
 def test_full_width_estimate_chain_and_batch8(dev, precision):
     from drmnet_amd.estimate import estimate, estimate_batch
 
@@ -224,7 +233,7 @@ def test_full_width_estimate_chain_and_batch8(dev, precision):
     e["envmap"] = rel_l2(env.cpu(), g["envmap"])
     print(f"full-width estimate chain ({precision}):", {k: f"{v:.2e}" for k, v in e.items()}, "steps", drm.last_steps, "zK", zK.tolist())
     assert e["cond"] < 1e-6 and max(e["inpaint"], e["LrK"], e["Lr0"], e["envmap"]) < 1e-4  # north-star tolerance, end to end (50 + K steps)
-    assert drm.last_steps == int(g["K"][0]) and np.allclose(zK.cpu().numpy(), g["zK"][0], atol=1e-5)
+    assert drm.last_steps == int(g["K"][0]) and np.allclose(zK.cpu().numpy(), g["zK"][0], atol=1e-5 if precision != "f16mx" else 1e-4)
 
     # configs[4]: a batch of objects through estimate_batch with early exit on.  Row 0 = the golden object with the golden draws; rows
     # 1..7 = the same object started from other x_T / step noise (different inpaintings -> different BRDF trajectories).

@@ -61,7 +61,7 @@ def tiny_models(g, dev):
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16mx"])
 def test_estimate_chain_vs_reference_trace(precision):
     from drmnet_amd.estimate import estimate
     from drmnet_amd.transform import hdr2ldr
@@ -97,5 +97,5 @@ def test_estimate_chain_vs_reference_trace(precision):
     log_err = np.abs(np.log10(Lr0.cpu().numpy() + 0.1) - np.log10(g["Lr0"] + 0.1)).max()
     assert log_err < 1e-4, log_err
     assert drm.last_steps == int(g["K"][0])
-    assert np.allclose(zK.cpu().numpy(), g["zK"][0], atol=1e-5, equal_nan=True)
+    assert np.allclose(zK.cpu().numpy(), g["zK"][0], atol=1e-5 if precision != "f16mx" else 1e-4, equal_nan=True)
     assert np.abs(ldr.astype(np.float64) - g["ldr"]).max() < 5e-3

@@ -12,7 +12,7 @@ that do not need a full-size oracle run:
 import pytest
 import torch
 
-from conftest import gold, rel_l2
+from conftest import NET_TOL as MODE_TOL, gold, rel_l2
 from oracle import unet as ou
 from test_gpu_nets import build, full_inputs
 
@@ -26,7 +26,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("precision", ["f16x3"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
 def test_batch32_rows_reproduce_the_single_sample_golden(dev, precision):
     gd = gold("full_illnet_128x256")
     m = build(ou.ILLNET_CFG, "unet", int(gd["seed"]), dev).set_precision(precision)
@@ -40,7 +40,8 @@ def test_batch32_rows_reproduce_the_single_sample_golden(dev, precision):
     assert tuple(out.shape) == (B, 3, 128, 256) and torch.isfinite(out).all()
     for r in (0, 2, 14, 30):
         e = rel_l2(out[r].cpu(), gd["out"][0])
-        assert e < NET_TOL, (r, e)
+        print(f"IllNet B=32 ({precision}) row {r}: {e:.2e}")
+        assert e < MODE_TOL[precision], (r, e)
     # odd rows all see the same flipped input; sums over rows are accumulated in a data-dependent atomic order only across
     # tiles of the same image, so rows agree to rounding of the fp64 statistics (not necessarily bit for bit)
     assert rel_l2(out[1].cpu(), out[31].cpu()) < 1e-6
@@ -54,20 +55,22 @@ def test_batch32_rows_reproduce_the_single_sample_golden(dev, precision):
     torch.cuda.empty_cache()
 
 
-def test_refnet_batch32_and_row_gather(dev):
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_refnet_batch32_and_row_gather(dev, precision):
     gd = gold("full_refnet_128x256")
-    m = build(ou.REFNET_CFG, "encoder", int(gd["seed"]), dev).set_precision("f16x3")
+    m = build(ou.REFNET_CFG, "encoder", int(gd["seed"]), dev).set_precision(precision)
     xc, _ = full_inputs(1, 128, 256)
     t = torch.from_numpy(gd["t"]).to(dev)
     B = 32
     xb = xc.repeat(B, 1, 1, 1).to(dev)
     out = m(xb, t.repeat(B))
-    assert rel_l2(out[0].cpu(), gd["out"][0]) < NET_TOL and rel_l2(out[31].cpu(), gd["out"][0]) < NET_TOL
+    assert rel_l2(out[0].cpu(), gd["out"][0]) < MODE_TOL[precision] and rel_l2(out[31].cpu(), gd["out"][0]) < MODE_TOL[precision]
     del m
     torch.cuda.empty_cache()
 
 
-def test_full_width_drmnet_loop_device_vs_host_driven(dev):
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_full_width_drmnet_loop_device_vs_host_driven(dev, precision):
     """Full-width RefNet + IllNet through both loop implementations at the config shape (128x128): the device-side loop
     behind drm_drmnet_sample and the host-driven one over drm_drmnet_step (return_intermediates) must agree row by row (the
     per-sample early-exit bookkeeping itself is pinned by the tiny-net reference traces in test_gpu_samplers.py)."""
@@ -89,7 +92,7 @@ def test_full_width_drmnet_loop_device_vs_host_driven(dev):
     sd["out.3.weight"] = sd["out.3.weight"] * 8.0
     sd["out.3.bias"] = torch.tensor([0.95, 0.9, 0.97, 0.92, 0.05, 0.9])
     m.refnet_model.diffusion_model.load_state_dict(sd)
-    m = m.to(dev).set_precision("f16x3")
+    m = m.to(dev).set_precision(precision)
     B = 6
     LrK = synth.synth_refmaps(B, 128, 128, 77).to(dev)
     g = torch.Generator().manual_seed(9)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import gold, rel_l2
+from conftest import ACCURATE_MODES, CONTRACT, gold, rel_l2
 from drmnet_amd import synth
 from oracle import unet as ou
 
@@ -37,7 +37,7 @@ def tiny_drmnet(g, dev):
     return m.to(dev)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ACCURATE_MODES)
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_drmnet_p_sample_loop_vs_reference_trace(dev, tag, precision):
     g = gold(f"drmnet_loop_{tag}")
@@ -46,10 +46,10 @@ def test_drmnet_p_sample_loop_vs_reference_trace(dev, tag, precision):
     n0 = torch.from_numpy(g["noise0"]).to(dev)
     sn = torch.from_numpy(g["step_noise"]).to(dev)
     Lr0, zK, K = m.p_sample_loop(LrK, [LrK], [LrK], verbose=False, noise0=n0, step_noise=sn)
-    print(f"drmnet loop {tag}: K={K.tolist()} steps={m.last_steps} rel_l2={rel_l2(Lr0.cpu(), g['Lr0']):.2e}")
+    print(f"drmnet loop {tag} ({precision}): K={K.tolist()} steps={m.last_steps} rel_l2={rel_l2(Lr0.cpu(), g['Lr0']):.2e}")
     assert K.cpu().tolist() == g["K"].tolist()
     assert np.array_equal(np.isnan(zK.cpu().numpy()), np.isnan(g["zK"]))
-    assert np.allclose(np.nan_to_num(zK.cpu().numpy()), np.nan_to_num(g["zK"]), atol=1e-5)
+    assert np.allclose(np.nan_to_num(zK.cpu().numpy()), np.nan_to_num(g["zK"]), atol=1e-5 if precision != "f16mx" else 1e-4)
     assert rel_l2(Lr0.cpu(), g["Lr0"]) < 1e-4
     assert m.last_steps == int(g["K"].max())
     # host-driven variant (per-step C-ABI entry point) returns the reference's intermediates layout
@@ -58,7 +58,7 @@ def test_drmnet_p_sample_loop_vs_reference_trace(dev, tag, precision):
     assert rel_l2(Lr0b.cpu(), g["Lr0"]) < 1e-4
     zk_steps = torch.stack(inter["zk_inter"]).cpu().numpy()
     assert zk_steps.shape == g["zk_steps"].shape
-    assert np.allclose(np.nan_to_num(zk_steps), np.nan_to_num(g["zk_steps"]), atol=2e-5)
+    assert np.allclose(np.nan_to_num(zk_steps), np.nan_to_num(g["zk_steps"]), atol=2e-5 if precision != "f16mx" else 1e-4)
     Lrk_steps = torch.stack(inter["Lrk_inter"][1:]).cpu()
     assert rel_l2(Lrk_steps, g["Lrk_steps"]) < 1e-4
 
@@ -86,7 +86,7 @@ def tiny_obsnet(dev):
     return m.to(dev)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ACCURATE_MODES)
 @pytest.mark.parametrize("eta", [0, 1])
 def test_ddim_sample_vs_reference_trace(dev, eta, precision):
     from drmnet_amd.ddim import DDIMSampler
@@ -99,23 +99,24 @@ def test_ddim_sample_vs_reference_trace(dev, eta, precision):
     e1 = rel_l2(x1.cpu(), g["x_inter"][0])
     x, inter = s.sample(50, cond.shape[0], (3, 16, 16), cond, eta=float(eta), x_T=x_T, verbose=False, noise=noise)
     e = rel_l2(x.cpu(), g["x"])
-    print(f"ddim eta={eta}: first step {e1:.2e}, 50 steps {e:.2e}")
-    assert e1 < 2e-5 and e < 1e-5  # 50 steps: observed 6.6e-7 (fp32) .. 2e-6
+    print(f"ddim eta={eta} ({precision}): first step {e1:.2e}, 50 steps {e:.2e}")
+    assert (e1 < 2e-5 and e < 1e-5) if precision != "f16mx" else (e1 < CONTRACT and e < CONTRACT)  # 50 steps: observed 6.6e-7 (fp32) .. 2e-6
     assert torch.equal(inter["x_inter"][0], x_T)
     # ObsNetDiffusion.sample_log(ddim=True) is the estimate.py entry point (scripts/estimate.py:72-79)
     y, _ = m.sample_log(cond=cond, batch_size=cond.shape[0], ddim=True, ddim_steps=50, eta=float(eta), x_T=x_T, noise=noise)
     assert torch.equal(y, x)
 
 
-def test_ddpm_ancestral_vs_reference_trace(dev):
+@pytest.mark.parametrize("precision", ACCURATE_MODES)
+def test_ddpm_ancestral_vs_reference_trace(dev, precision):
     g = gold("ddpm_trace")
-    m = tiny_obsnet(dev)
+    m = tiny_obsnet(dev).set_precision(precision)
     cond, x_T, noise = (torch.from_numpy(g[k]).to(dev) for k in ("cond", "x_T", "noise"))
     pred_x0, inter = m.p_sample_loop(cond, tuple(x_T.shape), return_intermediates=True, x_T=x_T, verbose=False, start_T=6, noise=noise)
     e_img = rel_l2(inter["x_inter"][-1].cpu(), g["x_inter"][-1])
     e_x0 = rel_l2(pred_x0.cpu(), g["pred_x0"])
-    print(f"ddpm 6 steps: img {e_img:.2e} pred_x0 {e_x0:.2e}")
-    assert e_img < 1e-5 and e_x0 < 1e-5
+    print(f"ddpm 6 steps ({precision}): img {e_img:.2e} pred_x0 {e_x0:.2e}")
+    assert (e_img < 1e-5 and e_x0 < 1e-5) if precision != "f16mx" else (e_img < CONTRACT and e_x0 < CONTRACT)
 
 
 def test_step_dropins_match_reference_named_methods(dev):
@@ -141,14 +142,15 @@ def test_step_dropins_match_reference_named_methods(dev):
     assert rel_l2(z_out.cpu(), z_ref) < 2e-5 and rel_l2(mean.cpu(), out_ref) < 2e-5
 
 
-def test_graph_replayed_chain_equals_eager_chain(dev):
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_graph_replayed_chain_equals_eager_chain(dev, precision):
     """drm_ddim_sample / drm_ddpm_sample: step 1 eager, step 2 captured, the rest replayed (per-step scalars in a device table)
     must be bit-identical to the all-eager chain, with injected noise and with the Philox stream."""
     from drmnet_amd import ops
     from drmnet_amd.ddim import DDIMSampler
 
     g = gold("ddim_trace_eta1")
-    m = tiny_obsnet(dev).set_precision("f16x3")
+    m = tiny_obsnet(dev).set_precision(precision)
     cond, x_T, noise = (torch.from_numpy(g[k]).to(dev) for k in ("cond", "x_T", "noise"))
     s = DDIMSampler(m)
     run = lambda **kw: s.sample(50, cond.shape[0], (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, **kw)[0]

@@ -672,6 +672,285 @@ def make_estimate_chain(full=False):
         print(f"  {k_}: min {float(v_.min()):.3e} max {float(v_.max()):.3e}")
 
 
+
+# ----------------------------------------------------------------------------- round 4: long chains, weight stress, EMA checkpoints, resize
+
+LONG_DRM = dict(T=150, gamma=0.97, epsilon=0.012, head_w_scale=25.0, ill_out_scale=0.02, head_off=0.05, B=6, gen_seed=43, input_seed=99)
+LONG_OBS = dict(T=1000, linear_start=1e-4, linear_end=2e-3, B=2, gen_seed=53, input_seed=98)
+
+
+def make_long_chains():
+    """The two loop lengths the shipped configs run, end to end through the reference's own loops on 16x16 tiny networks:
+    max_timesteps = 150 of DRMNet's reverse process (models/drmnet.py:782-847, configs/drmnet/eval_drmnet.yaml) with rows that leave
+    after 3 ... 148 steps and one that never converges, and the whole T = 1000 ancestral chain of ObsNetDiffusion.p_sample_loop
+    (models/obsnet.py:500-564 over ldm/models/diffusion/ddpm.py:1120-1167).  Inputs and draws are regenerable from the stored seeds
+    (torch CPU generator); only the reference's outputs are stored.  Random-weight networks are not denoisers: the IllNet head is
+    damped (values stored) and the ancestral chain runs a milder beta range than the shipped one (whose 1 / sqrt(abar_T) = 1e7
+    growth needs a trained eps), with the head undamped."""
+    import ldm.models.diffusion.ddpm as refddpm
+    import models.drmnet as refdrm
+
+    c = LONG_DRM
+    T, B = c["T"], c["B"]
+    m = tiny_drmnet(gamma=c["gamma"], epsilon=c["epsilon"], max_timesteps=T)
+    head = m.refnet_model.diffusion_model.out[3]
+    LrK = synth.synth_refmaps(B, 16, 16, c["input_seed"])
+    with torch.no_grad():
+        o = m.illnet_model.diffusion_model.out[2]
+        o.weight.mul_(c["ill_out_scale"])
+        o.bias.mul_(c["ill_out_scale"])
+        wpart = m.apply_model(m.refnet_model, LrK, 0, [LrK]) - head.bias
+        head_bias = m.z0 + c["head_off"] * torch.tensor([-1.0, -1, -1, -1, 1, -1]) - c["head_w_scale"] * wpart.mean(0)
+        head.weight.mul_(c["head_w_scale"])
+        head.bias.copy_(head_bias)
+    g = gen(c["gen_seed"])
+    noise0 = torch.randn(LrK.shape, generator=g)
+    step_noise = torch.randn((T,) + tuple(LrK.shape), generator=g)
+    state = {"call": 0, "active": torch.ones(B, dtype=torch.bool), "nc_idx": None, "step": 0, "margin": []}
+    orig_randn_like, orig_check = torch.randn_like, m.check_convergence
+
+    def check(zk):
+        conv = orig_check(zk)
+        idx = torch.where(state["active"])[0]
+        state["nc_idx"] = idx[~conv]
+        state["active"][idx[conv]] = False
+        state["margin"].append(float(((zk - m.z0).norm(dim=-1) / m.epsilon - 1).abs().min()))
+        return conv
+
+    def randn_like(t, **kw):
+        if state["call"] == 0:
+            state["call"] += 1
+            return noise0.clone()
+        out = step_noise[state["step"]][state["nc_idx"]]
+        assert out.shape == t.shape, (out.shape, t.shape)
+        state["step"] += 1
+        return out
+
+    m.check_convergence = check
+    refdrm.torch.randn_like = randn_like
+    try:
+        Lr0, zK, K, inter = m.p_sample_loop(LrK, [LrK], [LrK], return_intermediates=True, verbose=False, log_every_k=10)
+    finally:
+        refdrm.torch.randn_like = orig_randn_like
+    print(f"  drmnet 150-step loop: K = {K.tolist()}, zK nan rows = {torch.isnan(zK).any(dim=1).tolist()}, |Lr0| max {float(Lr0.abs().max()):.2f}, "
+          f"closest |zk - z0| / epsilon to 1 over all steps: {min(state['margin']):.3e}")
+    save("drmnet_loop_150", Lr0=Lr0, zK=zK, K=K, z0=m.z0, head_bias=head_bias, Lrk_steps=torch.stack(inter["Lrk_inter"][1:]),
+         zk_steps=torch.stack(inter["zk_inter"]), LrK_sum=synth.checksum(LrK), noise_sum=synth.checksum(step_noise), delta=0.025,
+         **{k: v for k, v in c.items()})
+
+    c = LONG_OBS
+    _, OBS, _, _ = rh.ref_classes()
+    cfg = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    cfg["unet_config"] = {"target": cfg["unet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    cfg.update(image_size=16, use_ema=False, linear_start=c["linear_start"], linear_end=c["linear_end"])
+    assert cfg["timesteps"] == c["T"]
+    obs = OBS(**cfg).eval()
+    synth.load_synth(obs.model.diffusion_model, 21)
+    B = c["B"]
+    g = gen(c["gen_seed"])
+    cond = synth.synth_refmaps(B, 16, 16, c["input_seed"]) * 2 - 1
+    x_T = torch.randn((B, 3, 16, 16), generator=g)
+    noise = torch.randn((c["T"], B, 3, 16, 16), generator=g)
+    ctr = {"i": 0}
+
+    def noise_like(shape, device, repeat=False):
+        out = noise[ctr["i"]]
+        ctr["i"] += 1
+        assert tuple(out.shape) == tuple(shape)
+        return out
+
+    o2 = refddpm.noise_like
+    refddpm.noise_like = noise_like
+    try:
+        pred_x0, inter = obs.p_sample_loop(cond, (B, 3, 16, 16), return_intermediates=True, x_T=x_T, verbose=False, log_every_t=100)
+    finally:
+        refddpm.noise_like = o2
+    assert ctr["i"] == c["T"]
+    print(f"  ancestral 1000-step chain: |x| max along the chain {[round(float(x.abs().max()), 2) for x in inter['x_inter']]}, abar_T {float(obs.alphas_cumprod[-1]):.3f}")
+    save("ddpm_trace_1000", x=inter["x_inter"][-1], pred_x0=pred_x0, x_inter=torch.stack(inter["x_inter"][1:]), cond_sum=synth.checksum(cond),
+         noise_sum=synth.checksum(noise), **{k: v for k, v in c.items()})
+
+
+def make_stress():
+    """Weight stress for the split arithmetic modes: the three shipped networks at full width with heavy-tailed
+    weights (Student-t, 4 degrees of freedom) and GroupNorm gains x 10 (drmnet_amd/synth.py rule="stress"), forwards of the
+    reference's own modules at 64x64 (and the metric shape's aspect at 32x64)."""
+    _, _, _, oa = rh.ref_classes()
+    for name, cfg, cls, seed in (("illnet", ou.ILLNET_CFG, oa.UNetModel, synth.SEED_ILLNET), ("refnet", ou.REFNET_CFG, oa.EncoderUNetModel, synth.SEED_REFNET),
+                                 ("obsnet", ou.OBSNET_CFG, oa.UNetModel, synth.SEED_OBSNET)):
+        m = cls(**cfg).eval()
+        synth.load_synth(m, seed + 100, rule="stress")
+        cs = synth.checksum(torch.cat([v.flatten() for v in m.state_dict().values()]))
+        arrs = {}
+        for n, h, w in ((1, 64, 64), (2, 32, 64)):
+            xc, t_emb = full_inputs(n, h, w)
+            t = torch.tensor([7, 981][:n], dtype=torch.long)
+            with torch.no_grad():
+                out = m(xc, t_emb=t_emb) if name == "illnet" else m(xc, t)
+            print(f"  stress {name} {n}x{h}x{w}: out std {out.std():.4f} absmax {out.abs().max():.3f}")
+            arrs[f"out_{n}x{h}x{w}"] = out
+        save(f"stress_{name}", seed=seed + 100, wsum=cs, t=torch.tensor([7, 981]), **arrs)
+
+
+def make_ema_ckpt():
+    """a15: checkpoints WRITTEN BY THE REFERENCE and sampled under the reference's ema_scope.  Both models are built by the
+    reference's own classes with use_ema=True (16x16 tiny networks), their live weights set by the synth rule, the LitEma shadows
+    (ldm/modules/ema.py:5-44) initialised from them and then moved by the reference's own decay update -- LitEma.forward called
+    three times on live weights perturbed in between, so decay follows num_updates (ema.py:24-44) -- and the whole state_dict
+    (live parameters, dot-less shadow buffers, decay, num_updates, schedule buffers) is written with torch.save({"state_dict": ...})
+    to tests/golden/*.ckpt (data: tensors only).  Recorded: p_sample_loop / sample_log outputs of the reference inside and outside
+    `with model.ema_scope():` (models/drmnet.py:242-258, ldm/models/diffusion/ddpm.py:189-202)."""
+    import ldm.models.diffusion.ddim as refddim
+    import models.drmnet as refdrm
+
+    DRM, OBS, DDIM, _ = rh.ref_classes()
+
+    def drift(module, ema, seed):
+        """three EMA updates of the reference, the live weights moving in between"""
+        g = gen(seed)
+        for _ in range(3):
+            with torch.no_grad():
+                for p in module.parameters():
+                    p.add_(0.05 * p.abs().mean() * torch.randn(p.shape, generator=g))
+            ema(module)
+
+    # ---- DRMNet
+    cfg = rh.load_yaml_params("configs/drmnet/eval_drmnet.yaml")["model"]["params"]
+    cfg.pop("ckpt_path")
+    cfg["illnet_config"] = {"target": cfg["illnet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    cfg["refnet_config"] = {"target": cfg["refnet_config"]["target"], "params": dict(ou.TINY_ENC_CFG)}
+    T = 6
+    cfg.update(image_size=16, gamma=0.9, epsilon=1e-3, max_timesteps=T, delta=0.025, use_ema=True)
+    m = DRM(**cfg).eval()
+    synth.load_synth(m.illnet_model.diffusion_model, 21)
+    synth.load_synth(m.refnet_model.diffusion_model, 22)
+    m.illnet_model.z_emb_layer.load_state_dict(synth.synth_state_dict([(k, tuple(v.shape)) for k, v in m.illnet_model.z_emb_layer.state_dict().items()], synth.SEED_ZEMB))
+    for wrapper, ema in ((m.illnet_model, m.illnet_model_ema), (m.refnet_model, m.refnet_model_ema)):
+        for name, p in wrapper.named_parameters():  # shadows start from the (synth) live weights, as at the start of training
+            getattr(ema, ema.m_name2s_name[name]).copy_(p.detach())
+    drift(m.illnet_model, m.illnet_model_ema, 301)
+    drift(m.refnet_model, m.refnet_model_ema, 302)
+    path = os.path.join(GOLD, "drmnet_tiny_ema.ckpt")
+    torch.save({"state_dict": m.state_dict()}, path)
+    print(f"  wrote drmnet_tiny_ema.ckpt ({os.path.getsize(path) / 1024:.0f} KiB), num_updates {int(m.illnet_model_ema.num_updates)}")
+    B = 3
+    LrK = synth.synth_refmaps(B, 16, 32, 5)
+    g = gen(9)
+    noise0 = torch.randn(LrK.shape, generator=g)
+    step_noise = torch.randn((T,) + tuple(LrK.shape), generator=g)
+    orig_randn_like = torch.randn_like
+
+    def run_loop():
+        state = {"call": 0, "step": 0}
+
+        def randn_like(t, **kw):  # epsilon = 1e-3: no row converges within T steps, every draw is the full batch
+            if state["call"] == 0:
+                state["call"] += 1
+                return noise0.clone()
+            out = step_noise[state["step"]]
+            assert out.shape == t.shape
+            state["step"] += 1
+            return out
+
+        refdrm.torch.randn_like = randn_like
+        try:
+            return m.p_sample_loop(LrK, [LrK], [LrK], verbose=False)
+        finally:
+            refdrm.torch.randn_like = orig_randn_like
+
+    live = run_loop()
+    with m.ema_scope("golden"):
+        inside = run_loop()
+        x = torch.cat([LrK, LrK], 1)
+        te = torch.randn((B, 32), generator=gen(10))
+        with torch.no_grad():
+            ill_ema = m.illnet_model.diffusion_model(x, t_emb=te)
+    after = run_loop()
+    assert torch.equal(after[0], live[0]) and not torch.equal(inside[0], live[0]) and live[2].tolist() == [T] * B
+    with torch.no_grad():
+        ill_live = m.illnet_model.diffusion_model(x, t_emb=te)
+    save("ema_drmnet", Lr0_live=live[0], Lr0_ema=inside[0], K=live[2], illnet_live=ill_live, illnet_ema=ill_ema, T=T, B=B, gamma=0.9, epsilon=1e-3,
+         delta=0.025, gen_seed=9, temb_seed=10, input_seed=5, num_updates=int(m.illnet_model_ema.num_updates), decay=float(m.illnet_model_ema.decay))
+
+    # ---- ObsNet
+    ocfg = rh.load_yaml_params("configs/obsnet/eval_obsnet.yaml")["model"]["params"]
+    ocfg.pop("ckpt_path")
+    ocfg["unet_config"] = {"target": ocfg["unet_config"]["target"], "params": dict(ou.TINY_UNET_CFG)}
+    ocfg.update(image_size=16, use_ema=True)
+    obs = OBS(**ocfg).eval()
+    synth.load_synth(obs.model.diffusion_model, 21)
+    for name, p in obs.model.named_parameters():
+        getattr(obs.model_ema, obs.model_ema.m_name2s_name[name]).copy_(p.detach())
+    drift(obs.model, obs.model_ema, 303)
+    path = os.path.join(GOLD, "obsnet_tiny_ema.ckpt")
+    torch.save({"state_dict": obs.state_dict()}, path)
+    print(f"  wrote obsnet_tiny_ema.ckpt ({os.path.getsize(path) / 1024:.0f} KiB)")
+    B = 2
+    g = gen(3)
+    cond = synth.synth_refmaps(B, 16, 16, 98) * 2 - 1
+    x_T = torch.randn((B, 3, 16, 16), generator=g)
+    noise = torch.randn((50, B, 3, 16, 16), generator=g)
+    ctr = {"i": 0}
+
+    def noise_like(shape, device, repeat=False):
+        out = noise[ctr["i"]]
+        ctr["i"] += 1
+        return out
+
+    o1 = refddim.noise_like
+    refddim.noise_like = noise_like
+
+    def run_ddim(steps=3):
+        """the first `steps` of the 50-step eta = 1 DDIM schedule through the reference's p_sample_ddim (ddim.py:206-259), under whatever weights are live"""
+        s = DDIM(obs)
+        s.make_schedule(ddim_num_steps=50, ddim_eta=1.0, verbose=False)
+        ctr["i"] = 0
+        x = x_T
+        with torch.no_grad():
+            for index in range(49, 49 - steps, -1):
+                ts = torch.full((B,), int(s.ddim_timesteps[index]), dtype=torch.long)
+                x, _ = s.p_sample_ddim(x, cond, ts, index=index)
+        return x
+
+    try:
+        live = run_ddim()
+        with obs.ema_scope("golden"):
+            inside = run_ddim()
+            with torch.no_grad():
+                eps_ema = obs.apply_model(x_T, torch.full((B,), 981, dtype=torch.long), cond)
+        assert torch.equal(run_ddim(), live) and not torch.equal(inside, live)
+    finally:
+        refddim.noise_like = o1
+    save("ema_obsnet", x_live=live, x_ema=inside, eps_ema=eps_ema, B=B, gen_seed=3, input_seed=98, steps=3)
+
+
+def make_resize():
+    """An actual resize in BaseDataset.transform (dataset/basedataset.py:29-50: torchvision.transforms.functional.resize to
+    (size, size), antialias=True; tools/refharness.py restates torchvision's tensor path over torch.nn.functional.interpolate) and
+    the nearest mask resize of get_cond_for_predict (models/obsnet.py:691), from the reference's own BaseDataset at sizes != input."""
+    rh.install_stubs()
+    from dataset.basedataset import BaseDataset
+
+    g = gen(81)
+    out = {}
+    hdr = torch.exp(torch.randn((2, 3, 40, 40), generator=g) * 1.2 - 1.0)
+    rect = torch.exp(torch.randn((3, 24, 56), generator=g) * 1.2 - 1.0)  # 3-D, non-square, non-integer scale
+    big = torch.exp(torch.randn((1, 3, 128, 128), generator=g) * 1.0 - 1.0)
+    out.update(hdr=hdr, rect=rect, big=big)
+    out["resize_only"] = BaseDataset(size=16, transform_func="resize").transform(hdr)
+    out["log_of_resized"] = BaseDataset(size=16, transform_func="log_resize").transform(hdr)       # log(resize(x))
+    out["resized_log"] = BaseDataset(size=16, transform_func="resize_log").transform(hdr)          # resize(log(x))
+    out["rect_16"] = BaseDataset(size=16, transform_func="resize").transform(rect)
+    out["rect_24"] = BaseDataset(size=24, transform_func="resize").transform(rect)                  # H unchanged, W 56 -> 24
+    out["big_48"] = BaseDataset(size=48, transform_func="resize").transform(big)                    # 128 -> 48 (scale 2.67)
+    out["bicubic_16"] = BaseDataset(size=16, transform_func="resizeBICUBIC").transform(hdr)
+    out["nearest_16"] = BaseDataset(size=16, transform_func="resizeNEAREST").transform(hdr)
+    mask = (torch.rand((2, 1, 40, 40), generator=g) > 0.5).float()
+    out.update(mask=mask, mask_16=torch.nn.functional.interpolate(mask, size=(16, 16)), mask_64=torch.nn.functional.interpolate(mask, size=(64, 64)),
+               mask_rect=torch.nn.functional.interpolate(mask[:, :, :24, :], size=(16, 16)))
+    save("resize", **out)
+
 STEPS = {
     "refmap": lambda oa: make_refmap(),
     "estimate_chain": lambda oa: make_estimate_chain(),
@@ -688,6 +967,10 @@ STEPS = {
     "full": lambda oa: make_full_nets(oa),
     "full_samplers": lambda oa: make_full_samplers(),
     "transforms": lambda oa: make_transforms(),
+    "long_chains": lambda oa: make_long_chains(),
+    "stress": lambda oa: make_stress(),
+    "ema_ckpt": lambda oa: make_ema_ckpt(),
+    "resize": lambda oa: make_resize(),
 }
 
 

@@ -73,11 +73,24 @@ def install_stubs() -> None:
 
     class _IM:
         BILINEAR = "bilinear"
+        BICUBIC = "bicubic"
+        NEAREST = "nearest"
 
     def _resize(x, size, interpolation=None, antialias=True):
+        """torchvision.transforms.functional.resize on a float tensor (torchvision 0.13.1, the reference's pin, functional_tensor.py
+        resize): torch.nn.functional.interpolate(img[None] if 3-D, size, mode, align_corners=False for bilinear / bicubic, antialias
+        for those two modes only) -- torchvision is absent from this image, its published tensor path is restated here so that the
+        reference's BaseDataset can run a real resize for the fixtures (tools/make_golden.py --only resize)."""
         if tuple(x.shape[-2:]) == tuple(size):
             return x
-        raise NotImplementedError("resize stub only supports the no-op case")
+        mode = str(interpolation).lower()
+        lead = x.shape[:-2]
+        flat = x.reshape(-1, 1, *x.shape[-2:]).float()
+        if mode in ("bilinear", "bicubic"):
+            out = torch.nn.functional.interpolate(flat, size=tuple(size), mode=mode, align_corners=False, antialias=bool(antialias))
+        else:
+            out = torch.nn.functional.interpolate(flat, size=tuple(size), mode=mode)
+        return out.reshape(*lead, *size)
 
     tv.transforms = _mod(
         "torchvision.transforms",
