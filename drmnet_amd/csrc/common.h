@@ -154,6 +154,7 @@ int launch_luminance_scale(const float* x, int B, int HW, float scaler, float* s
 int launch_mirmap2envmap(const float* mir, const float* basis, float* out, int B, int C, int H, int W, int OH, int OW, int log_interp, int nhwc,
                          hipStream_t s);
 int launch_hdr2ldr(const float* x, const unsigned char* mask, int HW, float alpha, float gamma, float* out, hipStream_t s);
+int launch_resize(const float* x, float* out, int planes, int IH, int IW, int OH, int OW, int mode, hipStream_t s);
 
 // misc kernels (misc.hip)
 // absmax_bits (optional): [N][pack_input_absmax_parts(H, W)] words, every one written: max |element| of one block of a packed image as fp32 bits

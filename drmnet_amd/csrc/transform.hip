@@ -264,4 +264,85 @@ int launch_hdr2ldr(const float* x, const unsigned char* mask, int HW, float alph
   return DRM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ resize
+// BaseDataset's "resize" map (dataset/basedataset.py:44-50): torchvision.transforms.functional.resize(x, (size, size), interpolation,
+// antialias=True) on a float tensor = torch.nn.functional.interpolate(mode, align_corners=False, antialias=True) -- ATen's separable
+// anti-aliased filter (aten/src/ATen/native/cpu/UpSampleKernel.cpp, _compute_indices_min_size_weights_aa; torchvision 0.13.1 /
+// torch 1.12.1 are the reference's pins): per output index i along an axis of scale s = in / out,
+//   support = (s >= 1 ? s : 1) * interp_size / 2,  centre = s (i + 0.5),  first = max(int(centre - support + 0.5), 0),
+//   count = min(int(centre + support + 0.5), in) - first,  w_j = filter((j + first - centre + 0.5) * (s >= 1 ? 1 / s : 1)) / sum,
+// filter = triangle (bilinear, interp_size 2) or Keys cubic a = -0.5 (bicubic, interp_size 4); the W axis is filtered first, then H,
+// each in fp32 in tap order, as ATen's two passes do.  MODE_NEAREST is `interpolate(x, size)` with its default mode, the mask
+// resize of ObsNetDiffusion.get_cond_for_predict (models/obsnet.py:691): src = min(int(floorf(dst * (float)in / out)), in - 1).
+enum ResizeMode { RESIZE_NEAREST = 0, RESIZE_BILINEAR_AA = 1, RESIZE_BICUBIC_AA = 2 };
+constexpr int RESIZE_MAX_TAPS = 96;  // per axis: covers scale <= 23 (bicubic) / 47 (bilinear)
+
+__device__ __forceinline__ float aa_filter(int mode, float x) {
+  x = fabsf(x);
+  if (mode == RESIZE_BILINEAR_AA) return x < 1.0f ? 1.0f - x : 0.0f;
+  const float a = -0.5f;
+  if (x < 1.0f) return ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+  if (x < 2.0f) return (((x - 5.0f) * x + 8.0f) * x - 4.0f) * a;
+  return 0.0f;
+}
+
+// taps of output index i along an axis: returns (first, count), weights (normalised) into w[]
+__device__ __forceinline__ void aa_taps(int mode, int i, int in_len, float scale, int& first, int& count, float* w) {
+  const float interp_half = mode == RESIZE_BILINEAR_AA ? 1.0f : 2.0f;
+  const float support = scale >= 1.0f ? interp_half * scale : interp_half;
+  const float invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  const float centre = scale * ((float)i + 0.5f);
+  first = max((int)(long long)(centre - support + 0.5f), 0);
+  count = min((int)(long long)(centre + support + 0.5f), in_len) - first;
+  count = min(count, RESIZE_MAX_TAPS);
+  float total = 0.0f;
+  for (int j = 0; j < count; ++j) {
+    w[j] = aa_filter(mode, ((float)(j + first) - centre + 0.5f) * invscale);
+    total += w[j];
+  }
+  if (total != 0.0f)
+    for (int j = 0; j < count; ++j) w[j] /= total;
+}
+
+// grid (blocks over OH * OW, planes): one thread per output element; its row of horizontal weights lives in LDS per block column set
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ out, int planes, int IH, int IW, int OH, int OW,
+                                                     int mode) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= OH * OW) return;
+  const int oy = o / OW, ox = o - oy * OW;
+  const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+  for (int p = blockIdx.y; p < planes; p += gridDim.y) {
+    const float* src = x + (long long)p * IH * IW;
+    float* dst = out + (long long)p * OH * OW;
+    if (mode == RESIZE_NEAREST) {
+      const int sy = min((int)floorf((float)oy * sh), IH - 1), sx = min((int)floorf((float)ox * sw), IW - 1);
+      dst[o] = src[(long long)sy * IW + sx];
+      continue;
+    }
+    float wx[RESIZE_MAX_TAPS], wy[RESIZE_MAX_TAPS];
+    int x0, nx, y0, ny;
+    aa_taps(mode, ox, IW, sw, x0, nx, wx);
+    aa_taps(mode, oy, IH, sh, y0, ny, wy);
+    float acc = 0.0f;
+    for (int j = 0; j < ny; ++j) {
+      const float* row = src + (long long)(y0 + j) * IW + x0;
+      float h = row[0] * wx[0];  // ATen's horizontal pass: t = src[0] w[0]; t += src[k] w[k]
+      for (int k = 1; k < nx; ++k) h += row[k] * wx[k];
+      acc = j == 0 ? h * wy[0] : acc + h * wy[j];
+    }
+    dst[o] = acc;
+  }
+}
+
+int launch_resize(const float* x, float* out, int planes, int IH, int IW, int OH, int OW, int mode, hipStream_t s) {
+  DRM_REQUIRE(x && out && planes > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "resize: shape");
+  DRM_REQUIRE(mode >= RESIZE_NEAREST && mode <= RESIZE_BICUBIC_AA, "resize: mode must be DRM_RESIZE_NEAREST / _BILINEAR_AA / _BICUBIC_AA");
+  const float half = mode == RESIZE_BICUBIC_AA ? 2.0f : 1.0f;
+  const float smax = fmaxf(fmaxf((float)IH / OH, (float)IW / OW), 1.0f);
+  DRM_REQUIRE(mode == RESIZE_NEAREST || 2.0f * half * smax + 2.0f <= (float)RESIZE_MAX_TAPS, "resize: down-scaling factor beyond the kernel's tap budget");
+  hipLaunchKernelGGL(resize_kernel, dim3((OH * OW + 255) / 256, std::min(planes, 4096)), dim3(256), 0, s, x, out, planes, IH, IW, OH, OW, mode);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
 }  // namespace drm

@@ -26,6 +26,12 @@ _TABLE = {
 }
 
 
+def _require_gpu(x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError("BaseDataset maps run on the GPU (drmnet_amd has no CPU path); got a CPU tensor")
+    return x.float().contiguous()
+
+
 class BaseDataset(torch.utils.data.Dataset):
     def __init__(self, size: int, transform_func: str = "log", clamp_before_exp: float = 0.0):
         self.size = size
@@ -104,11 +110,8 @@ class BaseDataset(torch.utils.data.Dataset):
                 if seg:
                     y = self._run(y, seg, dynamic_normalize=dynamic_normalize, mask=mask)
             elif y.shape[-1] != self.size or y.shape[-2] != self.size:
-                # the shipped path never gets here (refmaps are produced at `size`); an actual resize is torch glue, not a kernel
-                aa = seg in ("bilinear", "bicubic")
-                flat = y.float().reshape(-1, 1, *y.shape[-2:])
-                flat = torch.nn.functional.interpolate(flat, size=(self.size, self.size), mode=seg, antialias=aa, align_corners=False if aa else None)
-                y = flat.reshape(*y.shape[:-2], self.size, self.size)
+                # (the shipped path never gets here: refmaps are produced at `size`) torchvision's resize(..., antialias=True), :44-50
+                y = ops.resize(_require_gpu(y), (self.size, self.size), seg)
         if not y.is_cuda:
             raise RuntimeError("BaseDataset maps run on the GPU (drmnet_amd has no CPU path); got a CPU tensor")
         return y.float().contiguous()

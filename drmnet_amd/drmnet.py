@@ -28,19 +28,21 @@ from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma, ZEmbDiffusio
 # Constructor / YAML keys of the reference (models/drmnet.py:79-240) that steer only training, logging or dataset caches: accepted so that
 # configs/drmnet/*.yaml load unchanged, never read.  Any other unknown key is an error.
 _TRAINING_ONLY = frozenset({
-    "loss_type", "monitor", "scheduler_config", "cond_stage_trainable", "cond_stage_forward", "l_refmap_weight", "l_refcode_weight", "sigma",
+    "loss_type", "monitor", "scheduler_config", "cond_stage_trainable", "l_refmap_weight", "l_refcode_weight", "sigma",
     "train_with_zk_gt", "train_with_zk_gt_switch_epoch", "cache_refmap", "refmap_cache_root", "envmap_dir",
 })
 
 
 class DRMNet(nn.Module):
-    def __init__(self, illnet_config, refnet_config, *, renderer_config=None, max_timesteps: int = 250, ckpt_path: Optional[str] = None,
+    def __init__(self, illnet_config, refnet_config, renderer_config=None, max_timesteps: int = 250, *, ckpt_path: Optional[str] = None,
                  init_from_ckpt_verbose: bool = True, ignore_keys=(), use_ema: bool = True, input_key: str = "LrK", sigma_for_cond_xK: float = 0.0,
                  image_size: int = 128, channels: int = 3, log_every_k: int = 5, parameterization: str = "residual", concat_mode: bool = False,
                  conditioning_key: Optional[str] = None, scale_factor: float = 1.0, scale_by_std: bool = False, delta: float = 0.0125,
                  gamma: float = 0.9, epsilon: float = 0.001, brdf_param_names=("specular",), z0=(1.0,), model_emb_z: bool = True,
                  emb_z_crossattn: bool = False, refmap_input_scaler: Optional[float] = None, first_stage_config=None,
-                 cond_stage_config="__is_first_stage__", basis_r0: Optional[torch.Tensor] = None, **training_only):
+                 cond_stage_config="__is_first_stage__", basis_r0: Optional[torch.Tensor] = None, cond_stage_forward: Optional[str] = None,
+                 **training_only):
+        # (the leading four parameters keep the reference's positional order, models/drmnet.py:79-85: DRMNet(ill, ref, renderer_cfg, 250))
         super().__init__()
         unknown = sorted(set(training_only) - _TRAINING_ONLY)
         if unknown:
@@ -51,6 +53,10 @@ class DRMNet(nn.Module):
             raise AssertionError("This model only supports concat mode")
         if scale_by_std:
             raise NotImplementedError("scale_by_std is training-only")
+        if cond_stage_forward is not None:
+            # the reference reads it in get_learned_conditioning on the sampling path (models/drmnet.py:366-373): a config that sets it must
+            # not silently behave differently
+            raise NotImplementedError("cond_stage_forward: only the default (cond_stage_model.encode of the identity first stage) is on the shipped path")
         if cond_stage_config not in ("__is_first_stage__", "__is_unconditional__"):
             raise NotImplementedError("a separate cond_stage_config is not on the shipped path")
         # sampler constants (models/drmnet.py:782-847 reads them per step) and estimate.py's attribute surface

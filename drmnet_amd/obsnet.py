@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, ops
 from .config import instantiate_from_config
 from .wrappers import DiffusionWrapper, IdentityFirstStage, LitEma, ema_weights, load_checkpoint
 
@@ -59,7 +59,7 @@ def _drop_training_only(kwargs: dict, who: str) -> None:
 class DDPM(nn.Module):
     """The noise schedule + the wrapped eps-network (ddpm.py:59-231), inference half."""
 
-    def __init__(self, unet_config, *, timesteps=1000, beta_schedule="linear", ckpt_path=None, ignore_keys=(), load_only_unet=False, use_ema=True,
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", *, ckpt_path=None, ignore_keys=(), load_only_unet=False, use_ema=True,
                  image_size=256, channels=3, log_every_t=100, clip_denoised=True, linear_start=1e-4, linear_end=2e-2, given_betas=None,
                  v_posterior=0.0, conditioning_key=None, parameterization="eps", learn_logvar=False, **training_only):
         super().__init__()
@@ -142,7 +142,7 @@ class DDPM(nn.Module):
 class LatentDiffusion(DDPM):
     """DDPM + conditioning by concatenation behind an identity first stage (ddpm.py:439-512), inference half."""
 
-    def __init__(self, first_stage_config, cond_stage_config, *, num_timesteps_cond=None, cond_stage_key="image", concat_mode=True, cond_stage_forward=None,
+    def __init__(self, first_stage_config, cond_stage_config, num_timesteps_cond=None, cond_stage_key="image", *, concat_mode=True, cond_stage_forward=None,
                  conditioning_key=None, scale_factor=1.0, scale_by_std=False, ckpt_path=None, ignore_keys=(), **ddpm_kwargs):
         if scale_by_std:
             raise NotImplementedError("scale_by_std is training-only")
@@ -270,11 +270,14 @@ class LatentDiffusion(DDPM):
 class ObsNetDiffusion(LatentDiffusion):
     """inpainting class (models/obsnet.py:35)."""
 
-    def __init__(self, *, renderer_config=None, padding_mode="noise", ddim_steps: Optional[int] = None, ddim_eta: float = 1.0, noisy_observe: float = 0.0,
-                 init_from_ckpt_verbose=True, first_stage_config=None, cond_stage_config="__is_first_stage__", ckpt_path=None, ignore_keys=(), **kwargs):
+    def __init__(self, renderer_config=None, img_renderer_config=None, num_timesteps_cond=None, cond_stage_key="image", padding_mode="noise", *,
+                 ddim_steps: Optional[int] = None, ddim_eta: float = 1.0, noisy_observe: float = 0.0, init_from_ckpt_verbose=True, first_stage_config=None,
+                 cond_stage_config="__is_first_stage__", ckpt_path=None, ignore_keys=(), **kwargs):
+        # (the leading five parameters keep the reference's positional order, models/obsnet.py:38-44; img_renderer_config renders training
+        # images only and is never read)
         if first_stage_config is None:
             first_stage_config = {"target": "ldm.models.autoencoder.IdentityFirstStage"}
-        super().__init__(first_stage_config, cond_stage_config, **kwargs)
+        super().__init__(first_stage_config, cond_stage_config, num_timesteps_cond, cond_stage_key, **kwargs)
         self.renderer = instantiate_from_config(renderer_config) if renderer_config is not None else None
         self.padding_mode, self.noisy_observe = padding_mode, noisy_observe
         self.ddim_steps, self.ddim_eta = ddim_steps, ddim_eta
@@ -325,7 +328,8 @@ class ObsNetDiffusion(LatentDiffusion):
         if self.noisy_observe > 0:
             cond = self.noisy_observe * torch.randn_like(cond) + cond
         c = self.get_learned_conditioning(cond.to(self.device))
-        mask = torch.nn.functional.interpolate(mask, size=(self.image_size, self.image_size))
+        if tuple(mask.shape[-2:]) != (self.image_size, self.image_size):  # :691 (default mode: nearest); a no-op on the shipped configs
+            mask = ops.resize(mask, (self.image_size, self.image_size), "nearest")
         if self.padding_mode == "noise":
             nz = torch.randn_like(c) if noise is None else noise
             c = c + (1 - mask) * nz

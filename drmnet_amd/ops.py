@@ -218,3 +218,22 @@ def hdr2ldr(x, mask=None, alpha: float = 0.18, gamma: float = 2.2):
     with _dev(x):
         _lib.check(_lib.lib().drm_hdr2ldr(x.data_ptr(), _lib.ptr(m), x.shape[0] * x.shape[1], float(alpha), float(gamma), out.data_ptr(), _lib.stream_ptr(x.device)))
     return out
+
+
+RESIZE_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2}
+
+
+@torch.no_grad()
+def resize(x, size, mode: str = "bilinear"):
+    """dataset/basedataset.py:44-50 (anti-aliased bilinear / bicubic, align_corners=False) and models/obsnet.py:691 (nearest) on the last
+    two dimensions of a device tensor; every leading dimension is a plane."""
+    x = _lib.require_gpu_tensor(x, "x")
+    if mode not in RESIZE_MODES:
+        raise NotImplementedError(f"resize mode {mode!r} (drm_resize implements {sorted(RESIZE_MODES)})")
+    oh, ow = int(size[0]), int(size[1])
+    ih, iw = int(x.shape[-2]), int(x.shape[-1])
+    planes = x.numel() // (ih * iw)
+    out = torch.empty(tuple(x.shape[:-2]) + (oh, ow), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        _lib.check(_lib.lib().drm_resize(x.data_ptr(), out.data_ptr(), planes, ih, iw, oh, ow, RESIZE_MODES[mode], _lib.stream_ptr(x.device)))
+    return out

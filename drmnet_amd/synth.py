@@ -15,12 +15,17 @@ drawn from one CPU ``torch.Generator`` per network, consumed in
 torch's CPU generator is deterministic for a fixed torch version, so the GPU
 box regenerates bit-identical tensors from (ordered keys, shapes, seed).
 
-``rule="stress"`` is the weight-stress distribution of the f16mx parity tests
-(heavier tails, larger GroupNorm gains):
+``rule="stress:<gain>"`` is the weight-stress distribution of the f16mx parity
+tests (heavier tails, larger GroupNorm gains):
 
 * ``ndim >= 2``      -> Student-t, 4 degrees of freedom, unit variance, ``/ sqrt(fan_in)``
-* 1-D ``*.weight``   -> ``10 * (1 + 0.1 * randn)``       (GroupNorm gamma x 10)
+* 1-D ``*.weight``   -> ``gain * (1 + 0.1 * randn)``     (GroupNorm gamma x gain)
 * 1-D ``*.bias``     -> ``0.1 * randn``
+
+The fixtures use gain 3 (the fp32 reference still sits within 3e-6 of the same
+network evaluated in fp64, so "1e-4 from the reference" means something) and gain
+10 (attention logits x 100: the fp32 reference itself is 4e-4 .. 3e-2 away from
+fp64 -- there the HIP path is held to the reference's own distance from fp64).
 """
 from __future__ import annotations
 
@@ -37,12 +42,14 @@ SEED_INPUT = 1234
 
 
 STRESS_DOF = 4
-STRESS_GAIN = 10.0
 
 
 def synth_tensor(name: str, shape: Sequence[int], gen: torch.Generator, rule: str = "normal") -> torch.Tensor:
     shape = tuple(int(s) for s in shape)
-    if rule not in ("normal", "stress"):
+    gain = 1.0
+    if rule.startswith("stress:"):
+        rule, gain = "stress", float(rule.split(":", 1)[1])
+    elif rule != "normal":
         raise ValueError(rule)
     if len(shape) >= 2:
         fan_in = 1
@@ -50,12 +57,17 @@ def synth_tensor(name: str, shape: Sequence[int], gen: torch.Generator, rule: st
             fan_in *= s
         z = torch.randn(shape, generator=gen, dtype=torch.float32)
         if rule == "stress":  # t_4 = z / sqrt(chi2_4 / 4), variance 4 / (4 - 2) = 2
-            chi = torch.randn((STRESS_DOF,) + shape, generator=gen, dtype=torch.float32).square().mean(0)
-            z = z / chi.sqrt() / math.sqrt(STRESS_DOF / (STRESS_DOF - 2.0))
+            # elementwise IEEE operations only (no reduction kernel, whose summation order differs between host CPUs): the GPU box
+            # regenerates these weights bit for bit
+            c = torch.randn((STRESS_DOF,) + shape, generator=gen, dtype=torch.float32)
+            chi = c[0] * c[0]
+            for j in range(1, STRESS_DOF):
+                chi = chi + c[j] * c[j]
+            z = z / (chi * (1.0 / STRESS_DOF)).sqrt() * (1.0 / math.sqrt(STRESS_DOF / (STRESS_DOF - 2.0)))
         return z / math.sqrt(fan_in)
     if name.endswith("weight"):
         g = 1.0 + 0.1 * torch.randn(shape, generator=gen, dtype=torch.float32)
-        return g * STRESS_GAIN if rule == "stress" else g
+        return g * gain
     return 0.1 * torch.randn(shape, generator=gen, dtype=torch.float32)
 
 

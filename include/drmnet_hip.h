@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DRM_ABI_VERSION 2
+#define DRM_ABI_VERSION 3
 #define DRM_MAX_LEVELS 8
 
 int drm_abi_version(void);
@@ -257,6 +257,15 @@ int drm_mirmap2envmap(const float* mirmap, const float* basis, float* out, int B
                       int channels_last, void* stream);
 /* hdr2ldr (utils/tonemap.py:4-9): x [HW][3] one channels-last image, mask uint8[HW] or NULL -> out [HW][3] in [0, 1]. */
 int drm_hdr2ldr(const float* x, const uint8_t* mask, int HW, float alpha, float gamma, float* out, void* stream);
+/* The "resize" map of BaseDataset.transform (dataset/basedataset.py:44-50: torchvision.transforms.functional.resize(x, (size, size),
+ * interpolation, antialias=True) = torch's anti-aliased separable bilinear / bicubic filter, align_corners = False) and the nearest
+ * mask resize of ObsNetDiffusion.get_cond_for_predict (models/obsnet.py:691: torch.nn.functional.interpolate(mask, size)).
+ * x [planes][IH][IW] -> out [planes][OH][OW] fp32 (planes = every leading dimension flattened).  Down-scaling factors up to 23
+ * (bicubic) / 47 (bilinear); beyond that DRM_ERR_ARG. */
+#define DRM_RESIZE_NEAREST 0
+#define DRM_RESIZE_BILINEAR_AA 1
+#define DRM_RESIZE_BICUBIC_AA 2
+int drm_resize(const float* x, float* out, int planes, int IH, int IW, int OH, int OW, int mode, void* stream);
 
 #ifdef __cplusplus
 }

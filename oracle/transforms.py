@@ -6,7 +6,11 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this
   mirmap2envmap / thetaphi2xyz / xyz2thetaphi   utils/transform.py:17-89,106-144
   DRMNet.r0toenvmap                          models/drmnet.py:931-941
   hdr2ldr                                    utils/tonemap.py:4-9
-Pinned by tests/golden/transforms.npz (outputs of the reference's own functions; tools/make_golden.py make_transforms).
+  BaseDataset "resize" / mask resize         dataset/basedataset.py:44-50, models/obsnet.py:691
+Pinned by tests/golden/transforms.npz and resize.npz (outputs of the reference's own functions; tools/make_golden.py make_transforms /
+make_resize).  The resize itself lives in third-party code the reference calls (torchvision 0.13.1 functional.resize -> torch 1.12.1
+interpolate(antialias=True)): its published algorithm (ATen UpSampleKernel.cpp, _compute_indices_min_size_weights_aa) is restated in
+`resize` below as explicit per-axis weight matrices.
 """
 from __future__ import annotations
 
@@ -16,10 +20,49 @@ import numpy as np
 import torch
 
 
-def transform(x: torch.Tensor, func: str, mask=None, params=None):
+def _aa_filter(mode: str, x: np.ndarray) -> np.ndarray:
+    x = np.abs(x).astype(np.float32)
+    if mode == "bilinear":
+        return np.where(x < 1, 1 - x, 0).astype(np.float32)
+    a = np.float32(-0.5)
+    return np.where(x < 1, ((a + 2) * x - (a + 3)) * x * x + 1, np.where(x < 2, (((x - 5) * x + 8) * x - 4) * a, 0)).astype(np.float32)
+
+
+def resize_matrix(in_len: int, out_len: int, mode: str) -> np.ndarray:
+    """[out_len, in_len] fp32 weights of one axis: anti-aliased bilinear / bicubic (align_corners=False), or nearest (legacy floor rule)."""
+    W = np.zeros((out_len, in_len), dtype=np.float32)
+    scale = np.float32(in_len) / np.float32(out_len)
+    if mode == "nearest":
+        for i in range(out_len):
+            W[i, min(int(np.floor(np.float32(i) * scale)), in_len - 1)] = 1
+        return W
+    half = np.float32(1.0 if mode == "bilinear" else 2.0)
+    support = half * scale if scale >= 1 else half
+    inv = np.float32(1) / scale if scale >= 1 else np.float32(1)
+    for i in range(out_len):
+        centre = scale * (np.float32(i) + np.float32(0.5))
+        first = max(int(centre - support + np.float32(0.5)), 0)
+        count = min(int(centre + support + np.float32(0.5)), in_len) - first
+        w = _aa_filter(mode, (np.arange(count, dtype=np.float32) + np.float32(first) - centre + np.float32(0.5)) * inv)
+        total = w.sum(dtype=np.float32)
+        W[i, first:first + count] = w / total if total != 0 else w
+    return W
+
+
+def resize(x: torch.Tensor, size, mode: str = "bilinear") -> torch.Tensor:
+    """torchvision's resize(x, size, mode, antialias=True) on the last two dims (W filtered first, then H), or nearest."""
+    oh, ow = size
+    Wh = torch.from_numpy(resize_matrix(x.shape[-2], oh, mode))
+    Ww = torch.from_numpy(resize_matrix(x.shape[-1], ow, mode))
+    return torch.matmul(Wh, torch.matmul(x.float(), Ww.T))
+
+
+def transform(x: torch.Tensor, func: str, mask=None, params=None, size=None):
     """BaseDataset.transform with dynamic_normalize=True whenever a mask is given -> (y, (log10min, log10max) or None)."""
     for name in func.split("_")[::-1]:  # f_g = f(g(x)): rightmost first
         if name.startswith("resize"):
+            if size is not None and tuple(x.shape[-2:]) != (size, size):
+                x = resize(x, (size, size), "bilinear" if name == "resize" else name[6:].replace("-", "_").lower())
             continue  # no-op at the stored size (the only case on the shipped path)
         if name == "log":
             x = torch.log10(x + 0.1) + 1

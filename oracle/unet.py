@@ -205,6 +205,27 @@ def param_manifest(cfg: dict, kind: str) -> List[Tuple[str, Tuple[int, ...]]]:
 
 # ----------------------------------------------------------------------------- primitives
 
+# Working precision.  fp32 restates the reference (GroupNorm32 / the softmax cast to fp32, util.py:214-216, openaimodel.py:376).  fp64 is
+# the same arithmetic carried in double -- the yardstick of the weight-stress fixtures (tests/golden/stress_*.npz: `out64_*`), where two
+# fp32 evaluations of one network differ by up to 1e-4 and "distance from the fp32 reference" stops being a measure of correctness.
+_DT = torch.float32
+
+
+class working_dtype:
+    """with working_dtype(torch.float64): ... -- the forwards below run in that precision (parameters must be given in it)"""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _DT
+        self.prev, _DT = _DT, self.dtype
+
+    def __exit__(self, *exc):
+        global _DT
+        _DT = self.prev
+
+
 
 def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
     """util.py:151-171 -- cat(cos, sin), f_j = exp(-ln(max_period) * j / half)."""
@@ -214,12 +235,12 @@ def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
         emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
-    return emb
+    return emb.to(_DT)
 
 
 def group_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """util.py:214-216 GroupNorm32: fp32, 32 groups, eps 1e-5, affine."""
-    return F.group_norm(x.float(), GN_GROUPS, w, b, GN_EPS)
+    return F.group_norm(x.to(_DT), GN_GROUPS, w, b, GN_EPS)
 
 
 def silu(x: torch.Tensor) -> torch.Tensor:
@@ -245,12 +266,12 @@ def attention_block(P: Dict[str, torch.Tensor], a: Attn, x: torch.Tensor) -> tor
     p = a.prefix
     b, c, hh, ww = x.shape
     xf = x.reshape(b, c, hh * ww)
-    n = F.group_norm(xf.float(), GN_GROUPS, P[p + ".norm.weight"], P[p + ".norm.bias"], GN_EPS)
+    n = F.group_norm(xf.to(_DT), GN_GROUPS, P[p + ".norm.weight"], P[p + ".norm.bias"], GN_EPS)
     qkv = F.conv1d(n, P[p + ".qkv.weight"], P[p + ".qkv.bias"])
     q, k, v = qkv.split(c, dim=1)
     s = 1.0 / math.sqrt(math.sqrt(c))
     w = torch.einsum("bct,bcs->bts", q * s, k * s)
-    w = torch.softmax(w.float(), dim=-1)
+    w = torch.softmax(w.to(_DT), dim=-1)
     o = torch.einsum("bts,bcs->bct", w, v)
     o = F.conv1d(o, P[p + ".proj_out.weight"], P[p + ".proj_out.bias"])
     return (xf + o).reshape(b, c, hh, ww)
@@ -292,7 +313,7 @@ def unet_forward(
         t_emb = timestep_embedding(timesteps, topo.model_channels)
     emb = time_embed(P, t_emb)
     hs = []
-    h = x.float()
+    h = x.to(_DT)
     for b in topo.input_blocks:
         h = _run_layers(P, b, h, emb)
         hs.append(h)
@@ -308,7 +329,7 @@ def unet_forward(
 def encoder_forward(P: Dict[str, torch.Tensor], topo: Topology, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
     """EncoderUNetModel.forward, openaimodel.py:969-991, pool='adaptive' head :922-929."""
     emb = time_embed(P, timestep_embedding(timesteps, topo.model_channels))
-    h = x.float()
+    h = x.to(_DT)
     for b in topo.input_blocks:
         h = _run_layers(P, b, h, emb)
     h = _run_layers(P, topo.middle, h, emb)

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/drmnet_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == syms
-    assert L.drm_abi_version() == _lib.ABI_VERSION == 2
+    assert L.drm_abi_version() == _lib.ABI_VERSION == 3
 
 
 def table(cfg, kind):

@@ -166,3 +166,16 @@ def test_constructors_accept_training_keys_and_reject_unknown_ones():
         ObsNetDiffusion(**dict(oparams, not_a_key=True))
     with pytest.raises(NotImplementedError):
         ObsNetDiffusion(**dict(oparams, parameterization="x0"))
+    # reference-style positional calls (models/drmnet.py:79-85, ddpm.py:60-64, models/obsnet.py:38-44) and cond_stage_forward
+    rest = {k: v for k, v in base.items() if k not in ("illnet_config", "refnet_config", "renderer_config", "max_timesteps", "ckpt_path")}
+    mp = DRMNet(tiny_u, tiny_e, None, 17, **rest)
+    assert mp.max_timesteps == 17 and mp.renderer is None
+    with pytest.raises(NotImplementedError):
+        DRMNet(**dict(base, cond_stage_forward="encode"))
+    from drmnet_amd.obsnet import DDPM
+
+    d = DDPM(tiny_u, 200, "linear", use_ema=False, conditioning_key="concat")
+    assert d.num_timesteps == 200
+    orest = {k: v for k, v in oparams.items() if k not in ("cond_stage_key", "padding_mode", "ckpt_path")}
+    op = ObsNetDiffusion(None, None, None, "raw_refmap", "zeros", **orest)
+    assert op.cond_stage_key == "raw_refmap" and op.padding_mode == "zeros"

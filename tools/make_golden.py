@@ -774,13 +774,14 @@ def make_long_chains():
 
 def make_stress():
     """Weight stress for the split arithmetic modes: the three shipped networks at full width with heavy-tailed
-    weights (Student-t, 4 degrees of freedom) and GroupNorm gains x 10 (drmnet_amd/synth.py rule="stress"), forwards of the
-    reference's own modules at 64x64 (and the metric shape's aspect at 32x64)."""
+    weights (Student-t, 4 degrees of freedom) and GroupNorm gains x 3 and x 10 (drmnet_amd/synth.py rule="stress:<gain>"), forwards of
+    the reference's own modules at 64x64 (and the metric shape's aspect at 32x64)."""
     _, _, _, oa = rh.ref_classes()
-    for name, cfg, cls, seed in (("illnet", ou.ILLNET_CFG, oa.UNetModel, synth.SEED_ILLNET), ("refnet", ou.REFNET_CFG, oa.EncoderUNetModel, synth.SEED_REFNET),
-                                 ("obsnet", ou.OBSNET_CFG, oa.UNetModel, synth.SEED_OBSNET)):
+    for gain, (name, cfg, cls, seed) in ((g_, c_) for g_ in (3, 10) for c_ in (
+            ("illnet", ou.ILLNET_CFG, oa.UNetModel, synth.SEED_ILLNET), ("refnet", ou.REFNET_CFG, oa.EncoderUNetModel, synth.SEED_REFNET),
+            ("obsnet", ou.OBSNET_CFG, oa.UNetModel, synth.SEED_OBSNET))):
         m = cls(**cfg).eval()
-        synth.load_synth(m, seed + 100, rule="stress")
+        synth.load_synth(m, seed + 100, rule=f"stress:{gain}")
         cs = synth.checksum(torch.cat([v.flatten() for v in m.state_dict().values()]))
         arrs = {}
         for n, h, w in ((1, 64, 64), (2, 32, 64)):
@@ -788,9 +789,21 @@ def make_stress():
             t = torch.tensor([7, 981][:n], dtype=torch.long)
             with torch.no_grad():
                 out = m(xc, t_emb=t_emb) if name == "illnet" else m(xc, t)
-            print(f"  stress {name} {n}x{h}x{w}: out std {out.std():.4f} absmax {out.abs().max():.3f}")
+                # the same arithmetic in fp64 (the oracle, which every other fixture pins to the reference, carried in double): under these
+                # weights the fp32 forward itself carries rounding noise of 1e-5 .. 1e-4 -- two fp32 evaluations with different summation
+                # orders differ by that much -- so the fixture also holds the fp64 answer, the yardstick for "how far is fp32 from the
+                # truth" next to "how far is the HIP path".  (The reference's modules cast to fp32 inside GroupNorm32 and cannot run in fp64.)
+                kind = "encoder" if name == "refnet" else "unet"
+                P64 = {k: v.double() for k, v in m.state_dict().items()}
+                topo = ou.build_topology(cfg, kind)
+                with ou.working_dtype(torch.float64):
+                    out64 = (ou.unet_forward(P64, topo, xc.double(), t_emb=t_emb.double()) if name == "illnet" else
+                             ou.encoder_forward(P64, topo, xc.double(), t) if kind == "encoder" else ou.unet_forward(P64, topo, xc.double(), timesteps=t))
+            e = float((out.double() - out64).norm() / out64.norm())
+            print(f"  stress x{gain} {name} {n}x{h}x{w}: out std {out.std():.4f} absmax {out.abs().max():.3f}  fp32 vs fp64 reference: {e:.2e}")
             arrs[f"out_{n}x{h}x{w}"] = out
-        save(f"stress_{name}", seed=seed + 100, wsum=cs, t=torch.tensor([7, 981]), **arrs)
+            arrs[f"out64_{n}x{h}x{w}"] = out64
+        save(f"stress{gain}_{name}", seed=seed + 100, gain=gain, wsum=cs, t=torch.tensor([7, 981]), **arrs)
 
 
 def make_ema_ckpt():
