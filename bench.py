@@ -263,6 +263,18 @@ DOMINANT_VARIANTS = {"f16x3": "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 
                      "f16mx": "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 2, false, false>"}
 
 
+def profile_variants(L) -> dict:
+    """name -> {kind, launches, ms, flops, bytes}: the library profiler's per-instantiation totals (drm_profile_variants), as of the last collect"""
+    need = L.drm_profile_variants(None, 0)
+    buf = C.create_string_buffer(int(need) + 16)
+    L.drm_profile_variants(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, kind, n, ms, fl, by = line.split("\t")
+        out[name] = {"kind": int(kind), "launches": int(n), "ms": float(ms), "flops": float(fl), "bytes": float(by)}
+    return out
+
+
 def kernel_source_hash() -> str:
     import hashlib
 
@@ -289,6 +301,7 @@ def imported_traffic(applicable: bool, precision: str = "f16x3") -> dict:
             out["traffic_note"] = f"{rel} was measured on a different conv_split2.hip (sha {prof.get('conv_split2_sha16')}): not imported"
             return out
         out["traffic"] = k["hbm_bytes_per_launch_corrected"]
+        out["traffic_kernel"] = DOMINANT_VARIANT
         out["traffic_source"] = f"imported from {rel} (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch of {DOMINANT_VARIANT}; same kernel source, sha {prof['conv_split2_sha16']})"
         return out
     return out
@@ -307,31 +320,52 @@ def rank_aggregate(dt_local: float, units_local: float, dist=None, device=None):
     return float(t.item()), float(u.item())
 
 
-def self_launch(args) -> int:
+def self_launch(args, command=None, have=None, poll_s=0.2) -> int:
     """`python bench.py --gpus N` with no launcher around it: start one fresh child process per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set as torch.distributed.run would), wait for them, return the worst exit code.  Runs before this
     process has made any HIP call (torch.cuda.device_count() does not initialise the runtime): a process that has touched the GPU
-    must never be replaced or forked on this pool.  Rank 0's stdout (the JSON line) is inherited; other ranks' stdout is dropped."""
+    must never be replaced or forked on this pool.  Rank 0's stdout (the JSON line) is inherited; other ranks' stdout is dropped.
+    A rank that exits non-zero ends the job: the surviving ranks (parked at their next barrier, where rank 0 would otherwise wait
+    out the collective's timeout) are terminated by PID, so a failed rank yields rc != 0 and NO JSON line -- rank 0 prints it only
+    after the last barrier.  `command` / `have` are test hooks (the child command line; the visible GPU count)."""
     import socket
     import subprocess
 
     n = args.gpus
-    have = torch.cuda.device_count()
+    have = torch.cuda.device_count() if have is None else have
     if have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    command = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] if command is None else list(command)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+        procs.append(subprocess.Popen(command, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            rc = max(rc, abs(code))
+        if rc != 0 and live:  # a rank failed: the others can only hang at a barrier
+            for pr in live:
+                pr.terminate()
+            for pr in live:
+                try:
+                    pr.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    pr.wait()
+            print(f"bench.py: a rank exited with code {rc}; the remaining {len(live)} rank(s) were terminated, no result line", file=sys.stderr)
+            break
+        if live:
+            time.sleep(poll_s)
     return rc
 
 
@@ -375,7 +409,7 @@ def secondary_pass(args, model, dev):
     headline measurement: the DRMNet step at 128 refmaps per GPU (north-star: batch 1024 over 8 GPUs) and at batch 1 @128x128 (the
     reference's own use, scripts/estimate.py), the ObsNet DDIM-50 chain at batch 256 (configs[2]; fp32-accurate split mode and the
     reduced-precision f16 mode, eager and hipGraph replay), and the full chain object image -> Lr0 (configs[4], metric part 2:
-    "full-chain samples/sec") at 32 objects per GPU with per-stage device time."""
+    "full-chain samples/sec") at 64 objects per GPU (batch 512 over 8 GPUs) with per-stage device time."""
     import copy
 
     from drmnet_amd import ops
@@ -447,11 +481,11 @@ def secondary_pass(args, model, dev):
     del x, xT
     torch.cuda.empty_cache()
 
-    # ---- full chain (BASELINE configs[4]; metric part 2): 32 object images per GPU, 256x256 -> 128x128 refmaps
+    # ---- full chain (BASELINE configs[4]; metric part 2): 64 object images per GPU (batch 512 over 8 GPUs), 256x256 -> 128x128 refmaps
     obs.set_precision(acc)
     obs.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["data"]["params"]["predict"])
     model.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/drmnet/eval_drmnet.yaml"))["data"]["params"]["predict"])
-    B = 32
+    B = 64
     imgs, normals, masks = chain_inputs(B, dev)
     fc = {"objects_per_gpu": B, "refmap": "3x128x128 from 256x256 object images", "ddim_steps": obs.ddim_steps, "max_timesteps": model.max_timesteps}
     for tag, ee in (("early_exit_off", False), ("natural_early_exit", True)):
@@ -493,13 +527,13 @@ def secondary_pass(args, model, dev):
 
 def full_chain_all_ranks(args, model, dev, dist):
     """Metric part 2 at N GPUs ("full-chain samples/sec @1/8 GPU"): every rank runs the whole chain (object images -> refmaps -> ObsNet DDIM-50
-    -> DRMNet loop, early exit off so the work is countable) on its own 32 synthetic objects -- batches shard by object, no collective on the
+    -> DRMNet loop, early exit off so the work is countable) on its own 64 synthetic objects -- batches shard by object, no collective on the
     path -- bracketed by barriers; time = MAX over ranks, work = SUM (rank_aggregate).  Runs after the headline measurement, on N > 1 only
     (at N = 1 the `secondary.full_chain` object carries it with per-stage times).  A rank that fails still meets the others at every barrier."""
     from drmnet_amd.config import instantiate_from_config, load_config
     from drmnet_amd.estimate import estimate_batch
 
-    B, err, run = 32, None, None
+    B, err, run = 64, None, None  # configs[4]: batch 512 over 8 GPUs
     try:
         obs = build_models("obsnet", dev, args.precision)
         obs.ds = instantiate_from_config(load_config(os.path.join(ROOT, "configs/obsnet/eval_obsnet.yaml"))["data"]["params"]["predict"])
@@ -592,12 +626,14 @@ def main():
         print("bench.py: the sampler state went non-finite inside the timed region; the measurement is invalid", file=sys.stderr)
         sys.exit(3)
     timed = None
+    timed_variants = {}
     if profile:
         L.drm_profile_enable(0)
         K0 = 5
         tm, tf, tb, tn = (C.c_double * K0)(), (C.c_double * K0)(), (C.c_double * K0)(), (C.c_int64 * K0)()
         _lib.check(L.drm_profile_collect(tm, tf, tb, tn))
         timed = (tm[0], tf[0], tb[0], int(tn[0]))
+        timed_variants = profile_variants(L)  # per instantiation of the 3x3 family, inside the timed region
         # per-family breakdown: a second, UNTIMED pass of the same steps with every family instrumented
         L.drm_profile_reset()
         L.drm_profile_enable(1)
@@ -609,6 +645,7 @@ def main():
 
     roofline = None
     breakdown = None
+    extra = {}
     if profile:
         K = 5
         ms, fl, by, n = (C.c_double * K)(), (C.c_double * K)(), (C.c_double * K)(), (C.c_int64 * K)()
@@ -651,7 +688,38 @@ def main():
             # HBM traffic is a PMC quantity: it cannot be read from inside this process.  It is IMPORTED from the committed rocprofv3
             # --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/prof_round.sh -> profiles/rNN_pmc_hbm_traffic.json), per
             # launch of the dominant variant -- and only when that profile was taken on the kernel source this build was made from.
-            roofline.update(imported_traffic(split and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256), args.precision))
+            tr = imported_traffic(split and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256), args.precision)
+            # ... and it is set against the algorithmic bytes of THE SAME instantiation's launches (the library profiler's per-variant
+            # totals of the timed region), not the family mean over all 3x3 variants
+            dom = max(timed_variants.items(), key=lambda kv: kv[1]["ms"])[0] if timed_variants else None
+            if dom is not None:
+                dv = timed_variants[dom]
+                dv_ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
+                roofline["dominant_variant"] = {
+                    "kernel": dom, "launches": dv["launches"], "avg_launch_ms": round(dv["ms"] / dv["launches"], 4), "share_of_step_time": round(dv["ms"] * 1e-3 / dt, 3),
+                    "achieved": round(dv_ach, 2), "frac": round(dv_ach / peak, 4), "flops_per_launch": round(dv["flops"] / dv["launches"], 1),
+                    "algorithmic_bytes_per_launch": round(dv["bytes"] / dv["launches"], 1), "traffic": None, "traffic_ratio": None}
+                if tr.get("traffic") is not None and tr.get("traffic_kernel") == dom:
+                    roofline["dominant_variant"]["traffic"] = tr["traffic"]
+                    roofline["dominant_variant"]["traffic_ratio"] = round(tr["traffic"] / (dv["bytes"] / dv["launches"]), 3)
+            roofline["traffic"] = tr.get("traffic")
+            roofline["traffic_is_for"] = "dominant_variant (see that object for the matching algorithmic bytes and the ratio)" if tr.get("traffic") is not None else None
+            for k_ in ("traffic_source", "traffic_note"):
+                if k_ in tr:
+                    roofline[k_] = tr[k_]
+        # the two other matrix families of the step (second, untimed pass: every family instrumented)
+        for key_, k_idx, bound in (("roofline_conv1x1", 1, "hbm"), ("roofline_attention", 2, "mfma")):
+            if n[k_idx] > 0 and ms[k_idx] > 0:
+                tf_ = fl[k_idx] / (ms[k_idx] * 1e-3) / 1e12
+                gbs = by[k_idx] / (ms[k_idx] * 1e-3) / 1e9
+                mpeak = F16_MFMA_PEAK_TFLOPS if args.precision != "fp32" else FP32_MFMA_PEAK_TFLOPS
+                extra[key_] = ({"bound": "hbm", "kernel": "conv_split2_kernel<1,...> (skip_connection / qkv / proj_out 1x1 convs; HBM-bound at the top levels, staging-bound below)",
+                                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "tflops": round(tf_, 2)}
+                               if bound == "hbm" else
+                               {"bound": "mfma", "kernel": "attention core (S = q k^T, softmax, P v; scores through the workspace)", "achieved": round(tf_, 2), "peak": mpeak,
+                                "unit": "TFLOP/s", "frac": round(tf_ / mpeak, 4), "algorithmic_GBps": round(gbs, 1)})
+                extra[key_].update({"launches": int(n[k_idx]), "ms_per_step": round(ms[k_idx] / args.steps, 3), "traffic": None,
+                                    "measured_in": "second, untimed pass of the same steps with every family instrumented"})
 
     chain_all = None
     if (world > 1 or dist is not None) and args.workload == "drmnet_step" and args.precision in ("f16x3", "f16mx") and not args.no_secondary:
@@ -669,16 +737,21 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"fp32": "f32", "f16x3": "f32 via split f16x3 MFMA (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)",
-                      "f16": "f16 operands, fp32 accumulate (REDUCED PRECISION, ~1e-3 rel-L2: not the headline configuration)",
-                      "f16mx": "f32 via split f16 hi*hi + block-scaled fp8 (e4m3) cross terms on the GroupNorm-fed 3x3 convs, f16x3 elsewhere, fp32 accumulate "
-                               "(2.4e-5 .. 4e-5 rel-L2 per network against the reference, 2e-6 .. 9e-6 on the recorded sampler loops and the full chain: inside the 1e-4 contract; "
-                               "the f16x3 and exact-fp32 figures of the same run are in the f16x3 / strict_fp32 objects of this line)"}[args.precision],
+            "dtype": {"fp32": "f32", "f16x3": "f32-accurate split: f16 hi/lo x3 MFMA, fp32 acc", "f16": "f16 operands, fp32 acc (reduced precision)",
+                      "f16mx": "f32-accurate split: f16 hi*hi + e4m3 cross terms, fp32 acc"}[args.precision],
+            "dtype_note": {"fp32": "v_mfma_f32_32x32x2_f32, exact fp32 products",
+                           "f16x3": "every fp32 operand split into fp16 hi + lo, 3 MFMAs per product, fp32 accumulate: ~2e-6 rel-L2 against the reference (the fp32 tolerances)",
+                           "f16": "REDUCED PRECISION, ~1e-3 rel-L2: not the headline configuration",
+                           "f16mx": "f16x3 with the GroupNorm-fed 3x3 convs on fp16 hi*hi + ONE block-scaled fp8 (e4m3) MFMA for both cross terms; emulated fp32 with ~15-bit "
+                                    "products: 2.4e-5 .. 4.0e-5 rel-L2 per network against the reference at B = 1 .. 256, <= 5e-5 on the 150-step / 1000-step reference chains "
+                                    "(1e-4 contract; tests/test_gpu_*.py run every BASELINE-shaped case in this mode); the f16x3 and exact-fp32 figures of the same run are "
+                                    "in the f16x3 / strict_fp32 objects of this line"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": args.batch, "refmap": "3x128x128 (from 256x256 object images)" if args.workload == "estimate_chain" else f"3x{args.height}x{args.width}",
                        "weights": "seeded synthetic (no checkpoint offline)", "parallelism": f"batch-sharded x{world}, no collective",
                        "algorithmic_gflop_per_sample_step": gflop, "achieved_tflops_per_gpu": round(value / world * gflop / 1e3, 2)},
             "roofline": roofline,
+            **extra,
             "kernel_breakdown": breakdown,
             "kernel_breakdown_note": "conv3x3 row and the roofline object: HIP events inside the timed region; other rows: a second, untimed pass of the same steps with every kernel family instrumented",
         }

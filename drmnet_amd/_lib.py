@@ -29,7 +29,7 @@ SYMBOLS = [
     "drm_profile_enable", "drm_profile_reset", "drm_profile_collect", "drm_unet_set_precision", "drm_set_op_precision",
     "drm_refmap_workspace_bytes", "drm_refmap_mask_make", "drm_erode_mask",
     "drm_unet_load_params_set", "drm_unet_use_set", "drm_set_graph_replay", "drm_graph_launches",
-    "drm_map_chain", "drm_masked_log_range", "drm_luminance_scale", "drm_mirmap2envmap", "drm_hdr2ldr", "drm_resize",
+    "drm_map_chain", "drm_masked_log_range", "drm_luminance_scale", "drm_mirmap2envmap", "drm_hdr2ldr", "drm_resize", "drm_profile_variants",
 ]
 
 
@@ -111,6 +111,8 @@ def lib() -> C.CDLL:
     L.drm_mirmap2envmap.argtypes = [fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     L.drm_hdr2ldr.argtypes = [fp, u8p, i32, C.c_float, C.c_float, fp, vp]
     L.drm_resize.argtypes = [fp, fp, i32, i32, i32, i32, i32, i32, vp]
+    L.drm_profile_variants.argtypes = [C.c_char_p, C.c_size_t]
+    L.drm_profile_variants.restype = C.c_size_t
     if L.drm_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libdrmnet_hip.so ABI version {L.drm_abi_version()} != {ABI_VERSION}: rebuild with `python -m drmnet_amd.build`")
     _lib = L

@@ -481,6 +481,8 @@ int drm_hdr2ldr(const float* x, const uint8_t* mask, int HW, float alpha, float 
   return guarded([&]() -> int { return launch_hdr2ldr(x, mask, HW, alpha, gamma, out, static_cast<hipStream_t>(stream)); });
 }
 
+size_t drm_profile_variants(char* buf, size_t cap) { return prof_variants_text(buf, cap); }
+
 int drm_resize(const float* x, float* out, int planes, int IH, int IW, int OH, int OW, int mode, void* stream) {
   return guarded([&]() -> int { return launch_resize(x, out, planes, IH, IW, OH, OW, mode, static_cast<hipStream_t>(stream)); });
 }

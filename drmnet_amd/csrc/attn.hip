@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
 __global__ __launch_bounds__(256) void attn_scales_kernel(const double2* __restrict__ mom, int C, int T, float alpha, float* __restrict__ q_tab,
                                                           float* __restrict__ p_tab, float* __restrict__ zero_tab, float* __restrict__ qk_inv,
                                                           float* __restrict__ k_scale, float* __restrict__ k_inv, float* __restrict__ pv_inv,
-                                                          float* __restrict__ v_scale, float* __restrict__ v_inv, float* __restrict__ o_tab) {
+                                                          float* __restrict__ v_scale, float* __restrict__ v_inv, float* __restrict__ o_tab,
+                                                          float* __restrict__ q_scale /* [N] 2^kq, or null */) {
   __shared__ double red[3][4];
   __shared__ float s_q, s_v;
   const int n = blockIdx.x, t = threadIdx.x;
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(256) void attn_scales_kernel(const double2* __restr
     s_q = sc[0];
     s_v = sc[2];
     qk_inv[n] = alpha * iv[0];
+    if (q_scale) q_scale[n] = sc[0];
     k_scale[n] = sc[1];
     k_inv[n] = iv[1];
     pv_inv[n] = 1.0f / 4096.0f;
@@ -420,6 +422,19 @@ bool attention_conv_applicable(int T, int C, int H, int W, int terms) {
 
 int launch_conv_split(const ConvArgs& a, hipStream_t s);
 
+// (for attn_flash.hip: the per-image factor tables and the row-major pre-split image of q / k)
+void launch_attn_scales(const double2* mom, int N, int C, int T, float alpha, float* q_tab, float* p_tab, float* zero_tab, float* qk_inv, float* k_scale,
+                        float* k_inv, float* pv_inv, float* v_scale, float* v_inv, float* o_tab, float* q_scale, hipStream_t s) {
+  hipLaunchKernelGGL(attn_scales_kernel, dim3(N), dim3(256), 0, s, mom, C, T, alpha, q_tab, p_tab, zero_tab, qk_inv, k_scale, k_inv, pv_inv, v_scale, v_inv,
+                     o_tab, q_scale);
+}
+int launch_pack_attn_rows(const float* src, long long img_stride, int ld, const float* scale, float* dst, int rows, int cin, int N, hipStream_t s) {
+  const unsigned pb = (unsigned)std::min<size_t>(((size_t)rows * cin / 8 + 255) / 256, 4096);
+  hipLaunchKernelGGL(pack_attn_weight_kernel<true>, dim3(pb, N), dim3(256), 0, s, src, img_stride, ld, scale, reinterpret_cast<float4*>(dst), rows, cin);
+  DRM_HIP_CHECK(hipGetLastError());
+  return DRM_OK;
+}
+
 // qkv [N][T][3C] (+ its fused per-channel statistics), scores workspace [N][T][T], out [N][T][C], ws: attention_conv_workspace_floats
 // proj_guard (optional): receives the (scale, shift, inverse) tables that guard proj_out's read of `out`
 int launch_attention_conv(const float* qkv, const double2* qkv_mom, float* scores, float* out, float* ws, int N, int H, int W, int C, int terms,
@@ -439,7 +454,7 @@ int launch_attention_conv(const float* qkv, const double2* qkv_mom, float* score
   prof_tag(N, T, 1, C, C);
   ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C + 4.0 * T * T), s);  // one scope for the whole core
   hipLaunchKernelGGL(attn_scales_kernel, dim3(N), dim3(256), 0, s, qkv_mom, C, T, alpha, q_tab, p_tab, zero_tab, qk_inv, k_scale, k_inv, pv_inv,
-                     v_scale, v_inv, o_tab);
+                     v_scale, v_inv, o_tab, nullptr);
   DRM_HIP_CHECK(hipGetLastError());
   if (proj_guard) {
     proj_guard->gn_scale = o_tab;

@@ -1,0 +1,345 @@
+// Single-kernel spatial self-attention for the long-sequence level (reference: QKVAttentionLegacy.forward, openaimodel.py:365-381 with
+// n_heads = 1; ObsNet's ds = 4 level: T = 32 x 64 = 2048 keys at 3x128x256, C = 384): S = alpha q k^T, softmax over keys, O = P v, without
+// the [N, T, T] score matrix ever leaving the chip.  The three-launch form (attn.hip: S GEMM, row softmax, P v GEMM on the conv pipeline)
+// writes the scores once, reads and rewrites them once and reads them again: 2.1 GB of HBM traffic per attention block at batch 32 against
+// 0.4 GB of q / k / v / o.
+//
+// Structure (CDNA4): ONE wave per SIMD on the whole 512-entry register file -- 256-thread workgroup, 4 waves, each wave owns 32 queries:
+//   * S^T = k q^T (keys are the M rows, queries the N columns): in the 32x32 accumulator layout a lane holds ONE query (its column) and 16
+//     keys per block in registers, so the running row maximum / row sum of the online softmax are plain per-lane register arithmetic plus one
+//     lane ^ 32 exchange -- no LDS, no cross-wave traffic;
+//   * the probabilities go from the S^T accumulators straight into O^T = v^T P^T as its B operand (cdna_hip_programming.md 3 "An accumulator
+//     tile as the next MFMA's operand"): registers 8s .. 8s+7 of a block are the fragment of k-step s, in the key order 16s + 8(j>>2) + 4h +
+//     (j&3); v^T is packed in that order (pack_attn_v_perm_kernel), so P never touches LDS either;
+//   * accumulators: O^T = C/32 blocks (192 registers at C = 384) + S^T = 4 blocks (64) = the 256 AGPRs; MFMA A / B operands (k, q, v^T
+//     fragments from LDS, P fragments from conversions) stay in the 256 architectural VGPRs, which is all hipcc allows them;
+//   * k / q (per 32-channel chunk: 128 keys + the workgroup's 128 queries, hi + lo fp16 planes: 32 KiB) and v^T (per 16-key slab: C channels,
+//     hi + lo: 24 KiB at C = 384) stream global -> LDS by LDS-DMA from the pre-split images (per image one power of two, like every
+//     un-normalised operand of the split modes) into a ring of four 32-KiB slots, two steps ahead, retired by counted s_waitcnt vmcnt(N) + raw
+//     s_barrier (one per step; every wave issues the same number of DMA instructions per step, so the counts are compile-time constants);
+//   * arithmetic: the three-product fp16 split of every other matrix kernel here (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32
+//     accumulate) -- q, k, v AND the probabilities (scaled by 2^12 so that their lo halves stay normal) are split; TERMS = 1 (DRM_PREC_F16)
+//     keeps the hi product only.  exp through v_exp_f32 on (s - m) log2(e).
+// Work: per 128-key tile and workgroup 2 x 1152 MFMAs (q k^T and P v at C = 384); k, v and the workgroup's q are re-read from L2 / the
+// Infinity Cache per key tile (the q / k / v images of a batch-32 pass are 300 MB).
+#include <algorithm>
+#include <atomic>
+#include <utility>
+
+#include "common.h"
+#include "profiler.h"
+
+namespace drm {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+union F4H8 {
+  float4 f4;
+  f16x8 h8;
+};
+
+constexpr int FA_QT = 128;          // queries per workgroup: 4 waves x 32
+constexpr int FA_KT = 128;          // keys per tile
+constexpr int FA_SLOT_F4 = 2048;    // 32 KiB ring slot
+constexpr int FA_SLOTS = 4;
+constexpr int FA_AHEAD = 2;         // DMA runs this many steps ahead of the MFMAs
+constexpr float FA_PSCALE = 4096.0f;  // probabilities are staged as p * 2^12 (their fp16 lo halves stay normal down to p ~ 2^-26)
+
+template <int N>
+__device__ __forceinline__ void fa_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA instruction (64 lanes x 16 B, wave-uniform 64-bit base in SGPRs + 32-bit per-lane byte offset -> LDS bytes [lds_dst, +1 KiB)),
+// issued from inline asm so that hipcc neither drains vmcnt(0) in front of the LDS reads nor re-orders it; completion is tracked by the
+// counted waits (conv_split2.hip glds16s; cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void fa_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+template <int... I, typename F>
+__device__ __forceinline__ void fa_static_for(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+}  // namespace
+
+// q / k images: [C/32 chunks][8 planes: hi seg 0..3, lo seg 0..3][T rows][8 halfs] per image (pack_attn_weight_kernel<true> of attn.hip; seg =
+// slab * 2 + lane half); v image: [T/32 key chunks][8 planes][C channels][8 halfs] with the keys of a half-plane in accumulator order
+// (pack_attn_v_perm_kernel below).  out [N][T][C] fp32.  s_scale[n] = alpha 2^-kq 2^-kk, o_scale[n] = 2^-kv.
+// grid: N * T / 128 workgroups of 256 threads.
+template <int C, int TERMS>
+__global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __restrict__ qimg, const float4* __restrict__ kimg, const float4* __restrict__ vimg,
+                                                            float* __restrict__ out, const float* __restrict__ qk_inv, const float* __restrict__ k_inv,
+                                                            const float* __restrict__ v_inv, int N, int T) {
+  constexpr int CB = C / 32;                // channel blocks of O^T
+  constexpr int NCH = C / 32;               // k / q chunk steps per key tile
+  constexpr int NSL = FA_KT / 16;           // v slab steps per key tile
+  constexpr int NSTEP = NCH + NSL;
+  constexpr int PC = 32 / 4;                // DMA pieces per wave, chunk step: (8 k planes + 8 q planes) x 2 KiB = 32 x 1 KiB over 4 waves
+  constexpr int PV = (4 * C / 64) / 4;      // ... slab step: 4 planes x C x 16 B over 4 waves
+  static_assert(C % 64 == 0 && 4 * C * 16 <= FA_SLOT_F4 * 16 && CB * 16 + 64 <= 256, "C: whole 1-KiB pieces per wave, a slab fits a slot, accumulators fit the AGPRs");
+  extern __shared__ float4 lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  // workgroups b and b + 8 share an XCD (and its L2): the query tiles of one image are dealt to one XCD, so k / v of the image are fetched
+  // from HBM once per XCD that works on it
+  const int qtiles = T / FA_QT;
+  const int total = N * qtiles;
+  int logical = blockIdx.x;
+  if ((total & 7) == 0) logical = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int n = logical / qtiles, q0 = (logical % qtiles) * FA_QT;
+  const size_t img_f4 = (size_t)T * C / 4;  // float4 per image in each of the three images
+  const float4* qi = qimg + (size_t)n * img_f4;
+  const float4* ki = kimg + (size_t)n * img_f4;
+  const float4* vi = vimg + (size_t)n * img_f4;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds));
+  const unsigned voff = (unsigned)lane * 16u;
+  const int ntiles = T / FA_KT;
+
+  // DMA of a step, by its type (U = index inside the key tile: compile-time) and key tile; `gslot` = the step's running index (its ring slot).
+  // Every wave issues PC (chunk step) or PV (slab step) 1-KiB pieces: the counted waits below rely on that.
+  auto issue_chunk = [&](int kt, int u, int gslot) {
+    const unsigned slot = lds0 + (unsigned)(gslot & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u);
+#pragma unroll
+    for (int i = 0; i < PC; ++i) {
+      const int p = wave * PC + i;  // 0..31: [k | q][plane 8][half 2]
+      const int which = p >> 4, pl = (p >> 1) & 7, half = p & 1;
+      const float4* src = (which ? qi : ki) + ((size_t)(u * 8 + pl) * T + (which ? q0 : kt * FA_KT) + half * 64);
+      fa_glds16(src, voff, slot + (unsigned)p * 1024u);
+    }
+  };
+  auto issue_slab = [&](int kt, int sl, int gslot) {
+    const unsigned slot = lds0 + (unsigned)(gslot & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u);
+    const int kc = kt * (FA_KT / 32) + (sl >> 1), s = sl & 1;
+#pragma unroll
+    for (int i = 0; i < PV; ++i) {
+      const int p = wave * PV + i;  // [pp 4: hi h0, hi h1, lo h0, lo h1][C / 64 parts]
+      const int pp = p / (C / 64), part = p % (C / 64);
+      const int plane = (pp >> 1) * 4 + 2 * s + (pp & 1);
+      const float4* src = vi + ((size_t)(kc * 8 + plane) * C + part * 64);
+      fa_glds16(src, voff, slot + (unsigned)(pp * C + part * 64) * 16u);
+    }
+  };
+
+  f32x16 O[CB], S[4];
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[c][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // this lane's query (column r of the wave's 32), this lane half's 64 keys per tile for l
+  const float s_scale = qk_inv[n] * k_inv[n];
+  const float s2 = s_scale * 1.44269504088896340736f;  // scores in units of log2: p = 2^(s2 * acc - m)
+  F4H8 Ph[4][2], Pl[4][2];  // probabilities of the current tile as MFMA B fragments: [key block][k-step], hi and lo halves
+
+  static_assert(NCH >= FA_AHEAD && FA_AHEAD == 2 && (FA_SLOTS & (FA_SLOTS - 1)) == 0 && FA_SLOTS >= FA_AHEAD + 2, "prologue: the first two steps are chunk steps; ring arithmetic");
+  issue_chunk(0, 0, 0);
+  issue_chunk(0, 1, 1);
+  fa_wait_vmcnt<PC>();  // step 0 landed (step 1's pieces may still be in flight)
+  __builtin_amdgcn_s_barrier();
+
+  int g = 0;
+  for (int kt = 0; kt < ntiles; ++kt) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[b][e] = 0.f;
+    fa_static_for(std::make_integer_sequence<int, NSTEP>{}, [&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int u2 = (u + FA_AHEAD) % NSTEP;  // the step whose DMA goes out now (beyond the last tile: the first tile again -- a harmless re-read
+      {                                           // into a slot nobody reads any more)
+        int kt2 = kt + (u + FA_AHEAD >= NSTEP ? 1 : 0);
+        if (kt2 == ntiles) kt2 = 0;
+        if constexpr (u2 < NCH) issue_chunk(kt2, u2, g + FA_AHEAD); else issue_slab(kt2, u2 - NCH, g + FA_AHEAD);
+      }
+      const float4* sl = lds + (size_t)(g & (FA_SLOTS - 1)) * FA_SLOT_F4;
+      if constexpr (u < NCH) {
+        // ---- S^T += k_chunk q_chunk^T : A = k rows (keys), B = q columns (queries)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          F4H8 qh, ql;
+          qh.f4 = sl[1024 + (2 * s + h) * 128 + wave * 32 + r];
+          if (TERMS == 3) ql.f4 = sl[1024 + (4 + 2 * s + h) * 128 + wave * 32 + r];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            F4H8 kh, kl;
+            kh.f4 = sl[(2 * s + h) * 128 + b * 32 + r];
+            if (TERMS == 3) {
+              kl.f4 = sl[(4 + 2 * s + h) * 128 + b * 32 + r];
+              S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl.h8, qh.h8, S[b], 0, 0, 0);
+              S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh.h8, ql.h8, S[b], 0, 0, 0);
+            }
+            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh.h8, qh.h8, S[b], 0, 0, 0);
+          }
+        }
+        if constexpr (u == NCH - 1) {
+          // ---- online softmax of the tile, in registers: this lane's query, 64 of the tile's 128 keys per lane half
+          float mt = S[0][0];
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mt = fmaxf(mt, S[b][e]);
+          mt *= s2;  // (s2 > 0)
+          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          const float m_new = fmaxf(m_run, mt);
+          const float f = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 2^(-inf) = 0
+          m_run = m_new;
+          float sum = 0.f;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float p = __builtin_amdgcn_exp2f(S[b][8 * s + j] * s2 - m_new);
+                sum += p;
+                const float ps = p * FA_PSCALE;
+                const _Float16 hi = (_Float16)ps;
+                Ph[b][s].h8[j] = hi;
+                if (TERMS == 3) Pl[b][s].h8[j] = (_Float16)(ps - (float)hi);
+              }
+            }
+          }
+          l_run = l_run * f + sum;
+          if (__any(f != 1.0f)) {
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) O[c][e] *= f;
+          }
+        }
+      } else {
+        // ---- O^T += v^T_slab P^T_slab : A = v^T rows (channels), B = the probabilities of key block kb, k-step s
+        constexpr int slab = u - NCH, kb = slab >> 1, s = slab & 1;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+          F4H8 vh, vl;
+          vh.f4 = sl[h * C + c * 32 + r];
+          if (TERMS == 3) {
+            vl.f4 = sl[(2 + h) * C + c * 32 + r];
+            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.h8, Ph[kb][s].h8, O[c], 0, 0, 0);
+            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.h8, Pl[kb][s].h8, O[c], 0, 0, 0);
+          }
+          O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.h8, Ph[kb][s].h8, O[c], 0, 0, 0);
+        }
+      }
+      // the pieces of step g + 1 (issued one step ago) have landed for this wave; allowed in flight: the pieces of step g + 2 issued above
+      if constexpr (u2 < NCH) fa_wait_vmcnt<PC>(); else fa_wait_vmcnt<PV>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      ++g;
+    });
+  }
+  fa_wait_vmcnt<0>();  // drain the wrapped prefetches before the workgroup's LDS can be re-assigned
+
+  // ---- epilogue: O^T / (l 2^12 2^kv): this lane's query, channels c * 32 + 8 g4 + 4 h + {0..3} per register group
+  const float l = l_run + __shfl_xor(l_run, 32);
+  const float fo = v_inv[n] / (FA_PSCALE * l);
+  float* op = out + ((size_t)n * T + q0 + wave * 32 + r) * C;
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      *reinterpret_cast<float4*>(op + c * 32 + 8 * g4 + 4 * h) =
+          make_float4(O[c][4 * g4] * fo, O[c][4 * g4 + 1] * fo, O[c][4 * g4 + 2] * fo, O[c][4 * g4 + 3] * fo);
+}
+
+// v[n] ([T keys][ld] fp32, channel c at column c) * scale[n] -> the v^T image of attn_flash_kernel: [T/32 key chunks][8 planes: hi seg 0..3, lo seg
+// 0..3][C][8 halfs], seg = k-step s * 2 + lane half h, and half j of plane (s, h) holds key 32 kc + 16 s + 8 (j >> 2) + 4 h + (j & 3): the order in
+// which the S^T accumulator registers 8s .. 8s+7 of lane half h enumerate their keys.  A thread produces one hi + one lo entry (8 keys of one
+// channel); adjacent lanes take adjacent channels: every load is a coalesced row segment.   grid (blocks, N), block 256.
+__global__ __launch_bounds__(256) void pack_attn_v_perm_kernel(const float* __restrict__ src, long long img_stride, int ld, const float* __restrict__ scale,
+                                                               float4* __restrict__ dst, int C, int T) {
+  const int n = blockIdx.y;
+  const float sc = scale[n];
+  const float* sp = src + (size_t)n * img_stride;
+  float4* dp = dst + (size_t)n * ((size_t)C * T / 4);
+  const size_t units = (size_t)C * (T / 8);  // (channel, (key chunk, seg))
+  for (size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(u % C);
+    const int oct = (int)(u / C);  // key chunk * 4 + seg
+    const int kc = oct >> 2, seg = oct & 3, s = seg >> 1, hh = seg & 1;
+    F4H8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = 32 * kc + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+      const float v = __builtin_amdgcn_fmed3f(sp[(size_t)key * ld + c] * sc, -65504.0f, 65504.0f);
+      const _Float16 x = (_Float16)v;
+      hi.h8[j] = x;
+      lo.h8[j] = (_Float16)(v - (float)x);
+    }
+    dp[((size_t)kc * 8 + seg) * C + c] = hi.f4;
+    dp[((size_t)kc * 8 + 4 + seg) * C + c] = lo.f4;
+  }
+}
+
+bool attention_flash_applicable(int T, int C, int terms) { return (terms == 3 || terms == 1) && C == 384 && T % FA_KT == 0 && T >= 1024; }
+
+size_t attention_flash_workspace_floats(int N, int T, int C) {
+  const size_t Z = (size_t)(C > T ? C : T);
+  return 3 * (size_t)N * T * C + (size_t)N * (2 * C + T + Z) + 7 * (size_t)N + 64;
+}
+
+// (attn.hip)
+void launch_attn_scales(const double2* mom, int N, int C, int T, float alpha, float* q_tab, float* p_tab, float* zero_tab, float* qk_inv, float* k_scale,
+                        float* k_inv, float* pv_inv, float* v_scale, float* v_inv, float* o_tab, float* q_scale, hipStream_t s);
+int launch_pack_attn_rows(const float* src, long long img_stride, int ld, const float* scale, float* dst, int rows, int cin, int N, hipStream_t s);
+
+// qkv [N][T][3C] (+ its fused per-channel statistics), out [N][T][C], ws: attention_flash_workspace_floats.
+// proj_guard (optional): receives the (scale, shift, inverse) tables that guard proj_out's read of `out`, as launch_attention_conv does
+int launch_attention_flash(const float* qkv, const double2* qkv_mom, float* out, float* ws, int N, int T, int C, int terms, hipStream_t s, ConvArgs* proj_guard) {
+  DRM_REQUIRE(attention_flash_applicable(T, C, terms) && qkv_mom, "single-kernel attention: shape");
+  const size_t Z = (size_t)(C > T ? C : T);
+  float* wq = ws;                           // three pre-split images, T * C * 4 bytes per image each
+  float* wk = wq + (size_t)N * T * C;
+  float* wv = wk + (size_t)N * T * C;
+  float* q_tab = wv + (size_t)N * T * C;    // [N][C]   (tables of the conv-pipeline form: only o_tab / zero_tab / v_inv are read here, by proj_out)
+  float* p_tab = q_tab + (size_t)N * C;     // [N][T]
+  float* zero_tab = p_tab + (size_t)N * T;  // [N][max(C, T)]
+  float* o_tab = zero_tab + (size_t)N * Z;  // [N][C]
+  float* vec = o_tab + (size_t)N * C;       // 7 x [N]
+  float *qk_inv = vec, *k_scale = vec + N, *k_inv = vec + 2 * N, *pv_inv = vec + 3 * N, *v_scale = vec + 4 * N, *v_inv = vec + 5 * N, *q_scale = vec + 6 * N;
+  const float alpha = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, applied once to the dot product
+  prof_tag(N, T, 1, C, C);
+  ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C), s);  // algorithmic bytes: q, k, v in, o out
+  launch_attn_scales(qkv_mom, N, C, T, alpha, q_tab, p_tab, zero_tab, qk_inv, k_scale, k_inv, pv_inv, v_scale, v_inv, o_tab, q_scale, s);
+  DRM_HIP_CHECK(hipGetLastError());
+  if (proj_guard) {
+    proj_guard->gn_scale = o_tab;
+    proj_guard->gn_shift = zero_tab;
+    proj_guard->in_inv = v_inv;
+  }
+  const long long sq = (long long)T * 3 * C;
+  DRM_TRY(launch_pack_attn_rows(qkv, sq, 3 * C, q_scale, wq, T, C, N, s));
+  DRM_TRY(launch_pack_attn_rows(qkv + C, sq, 3 * C, k_scale, wk, T, C, N, s));
+  const unsigned pb = (unsigned)std::min<size_t>(((size_t)T * C / 8 + 255) / 256, 4096);
+  hipLaunchKernelGGL(pack_attn_v_perm_kernel, dim3(pb, N), dim3(256), 0, s, qkv + 2 * C, sq, 3 * C, v_scale, reinterpret_cast<float4*>(wv), C, T);
+  DRM_HIP_CHECK(hipGetLastError());
+  const size_t lds_bytes = (size_t)FA_SLOTS * FA_SLOT_F4 * sizeof(float4);
+  const DeviceInfo* di = device_info();
+  if (!di) return DRM_ERR_STATE;
+  auto go = [&](auto kern) -> int {
+    static std::atomic<uint64_t> attr_mask{0};
+    if (!(attr_mask.load(std::memory_order_acquire) >> di->ordinal & 1)) {
+      DRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      attr_mask.fetch_or(uint64_t(1) << di->ordinal, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(N * (T / FA_QT))), dim3(256), lds_bytes, s, reinterpret_cast<const float4*>(wq), reinterpret_cast<const float4*>(wk),
+                       reinterpret_cast<const float4*>(wv), out, qk_inv, k_inv, v_inv, N, T);
+    DRM_HIP_CHECK(hipGetLastError());
+    return DRM_OK;
+  };
+  if (terms == 1) return go(attn_flash_kernel<384, 1>);
+  return go(attn_flash_kernel<384, 3>);
+}
+
+}  // namespace drm

@@ -138,6 +138,10 @@ int launch_erode_mask(const unsigned char* mask, int H, int W, int k, unsigned c
 int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms = 0);
 // split-precision attention core on the fused 1x1 conv pipeline (per-image weights = k, v^T); T = H*W must be a multiple of 256
 bool attention_conv_applicable(int T, int C, int H, int W, int terms);
+// single-kernel form (attn_flash.hip): the long-sequence level (T >= 1024, C = 384), no score matrix in HBM
+bool attention_flash_applicable(int T, int C, int terms);
+size_t attention_flash_workspace_floats(int N, int T, int C);
+int launch_attention_flash(const float* qkv, const double2* qkv_mom, float* out, float* ws, int N, int T, int C, int terms, hipStream_t s, ConvArgs* proj_guard);
 // images per attention pass and the score workspace that takes ([group, T, T] floats: independent of the batch beyond one group)
 int attention_group(int N, int T);
 size_t attention_scores_floats(int N, int T);

@@ -25,6 +25,7 @@
 #include <utility>
 #include <vector>
 #include <cstdio>
+#include <string>
 
 #include "common.h"
 #include "profiler.h"
@@ -374,6 +375,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         areg[j][1] = ok ? f32x4{v[4], v[5], v[6], v[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
       } else if constexpr (TERMS == 2) {
         // eight fp16 hi halfs + the two fp8 images of the octet: al8 = e4m3((v - hi) * 2^(19-EA)), ah8 = e4m3(v * 2^(8-EA))
+        // The staged value itself is clamped to +-MX_A_LIM = 3584 (v_cvt_scalef32_pk_fp8_f32 makes NaN above 448 * 2^(EA-8); no GroupNorm + SiLU
+        // output gets near: |GN| <= sqrt(group size) * |gamma| + |beta|).  Clamping only the two fp8 images and leaving the fp16 hi operand on
+        // the +-65504 clamp of the other split modes was built and measured: two more v_med3 per value, 782 vs 792 steps/s on
+        // one box (-1.3 %) for a range no activation of these networks reaches -- not adopted; the limit is stated in include/drmnet_hip.h
+        // (DRM_PREC_F16MX) and tests/test_gpu_f16mx.py drives an input beyond it (finite, saturated).
         F4H8b hi;
         float c8[8], l8[8];
 #pragma unroll
@@ -1013,6 +1019,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           }
           __syncthreads();
           if (s_last_tile) {
+            // every wave of the finishing workgroup acquires for itself (one buffer_inv each): the slab loads below no longer lean on lane 0's
+            // invalidate having cleared the CU-wide L1 for the other waves (inside the HIP memory model now)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int col = wn * 32 + r, co = cur.co0 + col;
             const int cq = cur.co0 + wn * 32 + (r & ~3);
             float v[16];
@@ -1147,6 +1157,15 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     const double px = (double)a.N * a.H * a.W;
     const double px_in = (double)a.N * ((a.H >> a.up0) * (a.W >> a.up0)) * a.C0 + px * a.C1;
     prof_tag(a.N, a.H, a.W, a.C0 + a.C1, a.Cout);
+    if (prof_enabled()) {  // the instantiation's name as rocprofv3 prints it: per-variant totals next to the per-family ones
+      static const std::string vname = [] {
+        char b[192];
+        snprintf(b, sizeof b, "void drm::conv_split2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS,
+                 RAG ? "true" : "false", SK ? "true" : "false");
+        return std::string(b);
+      }();
+      prof_variant(vname.c_str());
+    }
     DRM_REQUIRE(a.w_img_stride_f4 == 0 || (C::TN == 1 && ks == 1), "per-image weights need one image per tile (H*W a multiple of the 256-pixel tile)");
     ProfScope ps(a.prof_kind == PROF_KINDS ? -1 : (a.prof_kind >= 0 ? a.prof_kind : (TAPS == 9 ? PROF_CONV3 : PROF_CONV1)), 2.0 * px * TAPS * cin * cout,
                  4.0 * (px_in + px * cout * (a.res ? 2 : 1) + (double)TAPS * cin * cout), s);

@@ -461,10 +461,11 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   DRM_TRY(gn_params(c, x, nullptr, Wb + l.n_w, Wb + l.n_b, sc, sh));
   Act qkv_act = new_act(c, 3 * C, H, W);  // its per-channel sums (fused into the qkv conv's epilogue) bound |v| >= |attention output|
   float* qkv = qkv_act.p;
-  float* scores = c.ar->alloc<float>(attention_scores_floats(c.N, T));  // one image group at a time (attn.hip attention_group)
+  const bool flash = c.split() && attention_flash_applicable(T, C, c.terms());  // the long-sequence level: one kernel, no score matrix (attn_flash.hip)
+  float* scores = flash ? nullptr : c.ar->alloc<float>(attention_scores_floats(c.N, T));  // one image group at a time (attn.hip attention_group)
   float* att = c.ar->alloc<float>((size_t)c.N * T * C);
-  const bool on_conv = c.split() && attention_conv_applicable(T, C, H, W, c.terms());  // the T >= 512 levels: both GEMMs on the conv pipeline
-  float* aws = on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C)) : nullptr;
+  const bool on_conv = flash || (c.split() && attention_conv_applicable(T, C, H, W, c.terms()));  // the T >= 512 levels: both GEMMs on the conv pipeline
+  float* aws = flash ? c.ar->alloc<float>(attention_flash_workspace_floats(c.N, T, C)) : on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C)) : nullptr;
   ConvArgs p;  // proj_out: 1x1 conv on the raw attention output, a convex combination of v rows: max |att| <= max |v|
   ConvArgs a;  // qkv: GroupNorm(x) -> 1x1
   a.C0 = C; a.N = c.N; a.H = H; a.W = W; a.taps = 1; a.Cout = 3 * C;
@@ -476,7 +477,8 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
     a.gn_scale = sc; a.gn_shift = sh; a.silu = 0;
     a.w = Wb + l.qkv_w; a.bias = Wb + l.qkv_b; a.out = qkv;
     DRM_TRY(run_conv(c, a, Wb, l.qkv_s, &qkv_act, wsq));
-    if (on_conv) DRM_TRY(launch_attention_conv(qkv, qkv_act.mom, scores, att, aws, c.N, H, W, C, c.terms(), c.s, &p));
+    if (flash) DRM_TRY(launch_attention_flash(qkv, qkv_act.mom, att, aws, c.N, T, C, c.terms(), c.s, &p));
+    else if (on_conv) DRM_TRY(launch_attention_conv(qkv, qkv_act.mom, scores, att, aws, c.N, H, W, C, c.terms(), c.s, &p));
     else DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split() ? c.terms() : 0));
   } else {
     qkv_act.mom_valid = true;  // sizing pass: the table is filled by the conv epilogue, no stand-alone moments launch

@@ -20,6 +20,12 @@ struct ProfScope {
 
 // optional shape tag (N,H,W,Cin,Cout) attached to the next ProfScope; DRM_PROF_DUMP=1 prints a per-shape table at collect
 void prof_tag(int n, int h, int w, int cin, int cout);
+// optional kernel-variant name (a string with static storage, the name rocprofv3 prints for the instantiation) attached to the next
+// ProfScope: per-variant totals next to the per-family ones, so that a measured per-launch figure (HBM traffic of ONE instantiation)
+// is compared with the algorithmic bytes of the same launches
+void prof_variant(const char* name);
+// "name\tkind\tlaunches\tms\tflops\tbytes\n" per variant seen since the last reset (after prof_collect); returns the bytes needed
+size_t prof_variants_text(char* buf, size_t cap);
 void prof_enable(int on);
 bool prof_enabled();
 // synchronises the recorded events and accumulates; returns per-kind totals since the last reset

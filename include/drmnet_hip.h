@@ -87,7 +87,11 @@ int drm_unet_use_set(drm_unet* net, int set);
  *       hi*hi on the f16 matrix cores + BOTH cross terms (hi*lo + lo*hi) in one block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, OCP
  *       e4m3 operands with power-of-two block factors): 2/3 of the matrix-pipe cycles of F16X3.  The cross terms are 2^-11 of a product and
  *       carry an e4m3 rounding: 7e-6 rel-L2 per res block, 2.4e-5 .. 4e-5 per network against the reference -- inside the 1e-4 contract
- *       (tests/test_gpu_f16mx.py), an order of magnitude above F16X3's ~2e-6.  Every other launch runs exactly as in F16X3. */
+ *       (tests/test_gpu_f16mx.py), an order of magnitude above F16X3's ~2e-6.  Every other launch runs exactly as in F16X3.
+ *       RANGE LIMIT of this mode: the input of such a conv AFTER GroupNorm + SiLU is clipped to +-3584 (= 448 * 2^3, the e4m3 image's range)
+ *       while it is staged -- F16X3 clips at fp16's 65504, FP32 not at all.  A GroupNorm output reaches at most sqrt(channels per group) *
+ *       |gamma| + |beta| (<= 7 |gamma| + |beta| here), so |gamma| would have to exceed ~500 before a value gets there; such an input comes out
+ *       finite and saturated, not wrapped or NaN.  Networks with GroupNorm gains of that size belong in F16X3. */
 #define DRM_PREC_F16MX 3
 int drm_unet_set_precision(drm_unet* net, int precision);
 int drm_set_op_precision(int precision);
@@ -200,6 +204,11 @@ int64_t drm_graph_launches(void);
 void drm_profile_enable(int on);
 void drm_profile_reset(void);
 int drm_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches);
+/* Per kernel INSTANTIATION of the conv families (the name rocprofv3 prints): one text line "name\tkind\tlaunches\tms\tflops\tbytes\n" each,
+ * totals since the last drm_profile_reset as of the last drm_profile_collect.  Writes at most cap - 1 characters + NUL into buf (may be
+ * NULL) and returns the size needed.  Lets a per-launch PMC figure of ONE instantiation (HBM bytes) be set against the algorithmic bytes
+ * of the same launches rather than a family mean. */
+size_t drm_profile_variants(char* buf, size_t cap);
 
 /* Standard-normal fill from the library's Philox4x32-10 stream (throughput mode noise source). */
 int drm_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);

@@ -103,3 +103,35 @@ def test_bench_aggregate_single_process_and_self_launch_refusal(capsys):
     if torch.cuda.device_count() < 2:
         assert bench.self_launch(argparse.Namespace(gpus=2)) == 2
         assert "GPU(s) are visible" in capsys.readouterr().err
+
+
+def test_a_failing_rank_ends_the_job_with_rc_and_no_result_line(tmp_path, capfd):
+    """under bench.py's own launcher a rank that dies must give rc != 0 and NO JSON line -- rank 0 prints the line only
+    after the last barrier, and the launcher terminates the ranks left parked there instead of waiting out the collective's timeout.  The
+    children here are stand-ins with the launcher's environment contract (RANK / WORLD_SIZE / MASTER_*): rank 1 fails, rank 0 would print a
+    result line after its 'barrier'."""
+    import argparse
+    import sys
+    import time
+
+    import bench
+
+    child = tmp_path / "rank.py"
+    child.write_text(
+        "import os, sys, time\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert world == 2 and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "mode = sys.argv[1]\n"
+        "if mode == 'fail' and rank == 1:\n"
+        "    sys.exit(3)\n"
+        "time.sleep(30 if mode == 'fail' else 0.2)  # rank 0 parked at the barrier the dead rank never reaches\n"
+        "if rank == 0:\n"
+        "    print('{\"metric\": \"x\"}', flush=True)\n")
+    t0 = time.time()
+    rc = bench.self_launch(argparse.Namespace(gpus=2), command=[sys.executable, str(child), "fail"], have=2, poll_s=0.05)
+    out = capfd.readouterr()
+    assert rc == 3 and time.time() - t0 < 15
+    assert '"metric"' not in out.out and "no result line" in out.err
+    rc = bench.self_launch(argparse.Namespace(gpus=2), command=[sys.executable, str(child), "ok"], have=2, poll_s=0.05)
+    out = capfd.readouterr()
+    assert rc == 0 and out.out.count('"metric"') == 1

@@ -10,7 +10,7 @@ OBJ="$ROOT/drmnet_amd/csrc/_obj"; OUT="$ROOT/drmnet_amd/csrc/_ab"; TMP="/tmp/drm
 mkdir -p "$OUT" "$TMP"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=off $EXTRA"
 objs=""
-for f in conv conv_split conv_split2 gn attn misc refmap transform engine samplers abi profiler; do
+for f in conv conv_split conv_split2 gn attn attn_flash misc refmap transform engine samplers abi profiler; do
   if [[ " $SRCS " == *" $f "* ]]; then
     hipcc $FLAGS ${VARIANT_REMARKS:+-Rpass-analysis=kernel-resource-usage} -c "$ROOT/drmnet_amd/csrc/$f.hip" -o "$TMP/$f.o" 2> "$TMP/$f.log" &
     objs="$objs $TMP/$f.o"

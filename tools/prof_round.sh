@@ -48,6 +48,18 @@ for k, (s, n) in sorted(fe.items(), key=lambda kv: -kv[1][0])[:12]:
     name = k.split('(')[0]
     res["kernels"][name] = {"launches": n, "fetch_kb_per_launch_raw": round(s / n, 1), "write_kb_per_launch": round(w_s / max(w_n, 1), 1),
                             "hbm_bytes_per_launch_corrected": int((2 * s / n + w_s / max(w_n, 1)) * 1024)}
+# the algorithmic bytes of the SAME instantiation's launches (bench.py's per-variant profiler totals of this run): the traffic ratio of the
+# dominant kernel compares like with like
+try:
+    bl = json.load(open(f'{OUT}/{tag}_bench_{prec}.json'))
+    dv = (bl.get("roofline") or {}).get("dominant_variant")
+    if dv and dv["kernel"] in res["kernels"]:
+        k = res["kernels"][dv["kernel"]]
+        k["algorithmic_bytes_per_launch"] = dv["algorithmic_bytes_per_launch"]
+        k["traffic_ratio"] = round(k["hbm_bytes_per_launch_corrected"] / dv["algorithmic_bytes_per_launch"], 3)
+        res["dominant_variant"] = dv["kernel"]
+except (OSError, ValueError, KeyError) as e:
+    res["dominant_variant_note"] = f"bench line not readable: {e}"
 json.dump(res, open(f'{OUT}/{tag}_pmc_hbm_traffic_{prec}.json', 'w'), indent=1)
 print(open(f'{OUT}/{tag}_bench_{prec}.json').read()[:400])
 for r in rows[:8]: print(r)
