@@ -45,7 +45,8 @@ constexpr int FA_KT = 128;          // keys per tile
 constexpr int FA_SLOT_F4 = 2048;    // 32 KiB ring slot
 constexpr int FA_SLOTS = 4;
 constexpr int FA_AHEAD = 2;         // DMA runs this many steps ahead of the MFMAs
-constexpr float FA_PSCALE = 4096.0f;  // probabilities are staged as p * 2^12 (their fp16 lo halves stay normal down to p ~ 2^-26)
+constexpr float FA_TAU = 6.0f;       // the softmax reference maximum is raised only when a tile exceeds it by more than 2^6 (lazy rescaling of O^T)
+constexpr float FA_PSCALE = 256.0f;  // probabilities (<= 2^FA_TAU) are staged as p * 2^8 <= 2^14 in fp16; their lo halves stay normal down to p ~ 2^-22
 
 template <int N>
 __device__ __forceinline__ void fa_wait_vmcnt() {
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
     }
   };
 
+  // per-lane byte offsets inside a slot: k rows (plane of lane half h, row r), q rows (+ this wave's 32 queries), v^T rows (plane h, channel r)
+  const unsigned lp_k = (unsigned)(h * 128 + r) * 16u, lp_q = (unsigned)(h * 128 + wave * 32 + r) * 16u, lp_v = (unsigned)(h * C + r) * 16u;
   f32x16 O[CB], S[4];
 #pragma unroll
   for (int c = 0; c < CB; ++c)
@@ -139,7 +142,6 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
   float m_run = -INFINITY, l_run = 0.f;  // this lane's query (column r of the wave's 32), this lane half's 64 keys per tile for l
   const float s_scale = qk_inv[n] * k_inv[n];
   const float s2 = s_scale * 1.44269504088896340736f;  // scores in units of log2: p = 2^(s2 * acc - m)
-  F4H8 Ph[4][2], Pl[4][2];  // probabilities of the current tile as MFMA B fragments: [key block][k-step], hi and lo halves
 
   static_assert(NCH >= FA_AHEAD && FA_AHEAD == 2 && (FA_SLOTS & (FA_SLOTS - 1)) == 0 && FA_SLOTS >= FA_AHEAD + 2, "prologue: the first two steps are chunk steps; ring arithmetic");
   issue_chunk(0, 0, 0);
@@ -161,20 +163,26 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
         if (kt2 == ntiles) kt2 = 0;
         if constexpr (u2 < NCH) issue_chunk(kt2, u2, g + FA_AHEAD); else issue_slab(kt2, u2 - NCH, g + FA_AHEAD);
       }
-      const float4* sl = lds + (size_t)(g & (FA_SLOTS - 1)) * FA_SLOT_F4;
+      // this step's slot as a running byte offset the compiler cannot see through: ONE address register per operand kind (+ immediate offsets)
+      // instead of a loop-invariant register per (slot, plane) pair beyond ds_read's 16-bit offset field -- those cost 14 spilled VGPRs whose
+      // reloads drained the DMA prefetch six times per key tile
+      unsigned slot_b = (unsigned)(g & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u);
+      asm volatile("" : "+s"(slot_b));
+      const char* slb = reinterpret_cast<const char*>(lds) + slot_b;
+      auto ld = [&](unsigned lane_part, int imm) { return *reinterpret_cast<const float4*>(slb + lane_part + imm); };
       if constexpr (u < NCH) {
         // ---- S^T += k_chunk q_chunk^T : A = k rows (keys), B = q columns (queries)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           F4H8 qh, ql;
-          qh.f4 = sl[1024 + (2 * s + h) * 128 + wave * 32 + r];
-          if (TERMS == 3) ql.f4 = sl[1024 + (4 + 2 * s + h) * 128 + wave * 32 + r];
+          qh.f4 = ld(lp_q, (1024 + 2 * s * 128) * 16);
+          if (TERMS == 3) ql.f4 = ld(lp_q, (1024 + (4 + 2 * s) * 128) * 16);
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             F4H8 kh, kl;
-            kh.f4 = sl[(2 * s + h) * 128 + b * 32 + r];
+            kh.f4 = ld(lp_k, (2 * s * 128 + b * 32) * 16);
             if (TERMS == 3) {
-              kl.f4 = sl[(4 + 2 * s + h) * 128 + b * 32 + r];
+              kl.f4 = ld(lp_k, ((4 + 2 * s) * 128 + b * 32) * 16);
               S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl.h8, qh.h8, S[b], 0, 0, 0);
               S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh.h8, ql.h8, S[b], 0, 0, 0);
             }
@@ -182,7 +190,10 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
           }
         }
         if constexpr (u == NCH - 1) {
-          // ---- online softmax of the tile, in registers: this lane's query, 64 of the tile's 128 keys per lane half
+          // ---- online softmax of the tile, in registers: this lane's query, 64 of the tile's 128 keys per lane half.  The reference maximum
+          // m_run is raised (and O^T rescaled: 3 x 192 register moves through the VGPRs) only when the tile's maximum exceeds it by more than
+          // FA_TAU (in log2 units): below that the probabilities are simply 2^(s - m_run) <= 2^FA_TAU -- the final O / l does not depend on
+          // which reference was used, and the fp16 staging of the probabilities (x FA_PSCALE) has the head-room for it
           float mt = S[0][0];
 #pragma unroll
           for (int b = 0; b < 4; ++b)
@@ -190,47 +201,52 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
             for (int e = 0; e < 16; ++e) mt = fmaxf(mt, S[b][e]);
           mt *= s2;  // (s2 > 0)
           mt = fmaxf(mt, __shfl_xor(mt, 32));
-          const float m_new = fmaxf(m_run, mt);
-          const float f = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 2^(-inf) = 0
-          m_run = m_new;
-          float sum = 0.f;
+          const bool raise = mt > m_run + FA_TAU;
+          if (__any(raise)) {  // (wave-uniform branch; lanes that do not raise rescale by 1)
+            const float m_new = raise ? mt : m_run;
+            const float f = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 2^(-inf) = 0
+            m_run = m_new;
+            l_run *= f;
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float p = __builtin_amdgcn_exp2f(S[b][8 * s + j] * s2 - m_new);
-                sum += p;
-                const float ps = p * FA_PSCALE;
-                const _Float16 hi = (_Float16)ps;
-                Ph[b][s].h8[j] = hi;
-                if (TERMS == 3) Pl[b][s].h8[j] = (_Float16)(ps - (float)hi);
-              }
-            }
-          }
-          l_run = l_run * f + sum;
-          if (__any(f != 1.0f)) {
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
+            for (int c = 0; c < CB; ++c) {
 #pragma unroll
               for (int e = 0; e < 16; ++e) O[c][e] *= f;
+              __builtin_amdgcn_sched_barrier(0);  // one block at a time through the VGPRs (the scheduler otherwise hoists all 192 reads)
+            }
           }
+          // The raw scores stay in the S^T accumulators: every slab step below turns the eight it needs into probabilities (exp, row-sum
+          // share, fp16 hi / lo split) between its MFMAs.  The empty asm pins them to the accumulator file here -- without it the compiler keeps
+          // the 64 values it has just read for the maximum (and then the 64 probabilities) in VGPRs through the whole P v phase: 128 of the
+          // 256 architectural registers, and spills around them.
+#pragma unroll
+          for (int b = 0; b < 4; ++b) asm volatile("" : "+a"(S[b]));
         }
       } else {
         // ---- O^T += v^T_slab P^T_slab : A = v^T rows (channels), B = the probabilities of key block kb, k-step s
         constexpr int slab = u - NCH, kb = slab >> 1, s = slab & 1;
+        F4H8 ph, pl;  // registers 8s .. 8s+7 of key block kb: the B fragment of this k-step (keys in accumulator order, as v^T is packed)
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pr = __builtin_amdgcn_exp2f(S[kb][8 * s + j] * s2 - m_run);
+          psum += pr;
+          const float ps = pr * FA_PSCALE;
+          const _Float16 hi = (_Float16)ps;
+          ph.h8[j] = hi;
+          if (TERMS == 3) pl.h8[j] = (_Float16)(ps - (float)hi);
+        }
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
           F4H8 vh, vl;
-          vh.f4 = sl[h * C + c * 32 + r];
+          vh.f4 = ld(lp_v, c * 32 * 16);
           if (TERMS == 3) {
-            vl.f4 = sl[(2 + h) * C + c * 32 + r];
-            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.h8, Ph[kb][s].h8, O[c], 0, 0, 0);
-            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.h8, Pl[kb][s].h8, O[c], 0, 0, 0);
+            vl.f4 = ld(lp_v, (2 * C + c * 32) * 16);
+            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.h8, ph.h8, O[c], 0, 0, 0);
+            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.h8, pl.h8, O[c], 0, 0, 0);
           }
-          O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.h8, Ph[kb][s].h8, O[c], 0, 0, 0);
+          O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.h8, ph.h8, O[c], 0, 0, 0);
         }
+        l_run += psum;
       }
       // the pieces of step g + 1 (issued one step ago) have landed for this wave; allowed in flight: the pieces of step g + 2 issued above
       if constexpr (u2 < NCH) fa_wait_vmcnt<PC>(); else fa_wait_vmcnt<PV>();
