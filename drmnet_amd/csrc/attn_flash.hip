@@ -44,7 +44,7 @@ constexpr int FA_QT = 128;          // queries per workgroup: 4 waves x 32
 constexpr int FA_KT = 128;          // keys per tile
 constexpr int FA_SLOT_F4 = 2048;    // 32 KiB ring slot
 constexpr int FA_SLOTS = 4;
-constexpr int FA_AHEAD = 2;         // DMA runs this many steps ahead of the MFMAs
+constexpr int FA_AHEAD = 3;         // DMA runs this many steps ahead of the MFMAs (a step is confirmed one step before its first fragment read)
 constexpr float FA_TAU = 6.0f;       // the softmax reference maximum is raised only when a tile exceeds it by more than 2^6 (lazy rescaling of O^T)
 constexpr float FA_PSCALE = 256.0f;  // probabilities (<= 2^FA_TAU) are staged as p * 2^8 <= 2^14 in fp16; their lo halves stay normal down to p ~ 2^-22
 
@@ -62,6 +62,18 @@ __device__ __forceinline__ void fa_glds16(const void* sbase, unsigned voff, unsi
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+// ... with an immediate byte offset (0 .. 4095).  Measured (tools/probes/glds_offset_probe.hip): the instruction offset moves BOTH sides -- the
+// global source and the LDS destination (M0 + offset + 16 * lane) -- so pieces whose source and destination advance together share one base pair.
+template <int IMM>
+__device__ __forceinline__ void fa_glds16i(const void* sbase, unsigned voff, unsigned lds_dst) {
+  static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(IMM)
                : "memory");
 }
 
@@ -107,28 +119,37 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
   const unsigned voff = (unsigned)lane * 16u;
   const int ntiles = T / FA_KT;
 
-  // DMA of a step, by its type (U = index inside the key tile: compile-time) and key tile; `gslot` = the step's running index (its ring slot).
-  // Every wave issues PC (chunk step) or PV (slab step) 1-KiB pieces: the counted waits below rely on that.
-  auto issue_chunk = [&](int kt, int u, int gslot) {
-    const unsigned slot = lds0 + (unsigned)(gslot & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u);
-#pragma unroll
-    for (int i = 0; i < PC; ++i) {
-      const int p = wave * PC + i;  // 0..31: [k | q][plane 8][half 2]
-      const int which = p >> 4, pl = (p >> 1) & 7, half = p & 1;
-      const float4* src = (which ? qi : ki) + ((size_t)(u * 8 + pl) * T + (which ? q0 : kt * FA_KT) + half * 64);
-      fa_glds16(src, voff, slot + (unsigned)p * 1024u);
-    }
+  // ---- DMA of a step.  Every wave issues PC (chunk step) or PV (slab step) 1-KiB pieces: the counted waits below rely on that.  The addresses are
+  // wave-uniform: a wave owns four consecutive planes of k (waves 0, 1) or of q (waves 2, 3) in a chunk step, and one plane of v^T in a slab
+  // step, so a step needs one or two 64-bit bases and immediate offsets.
+  const size_t rowbytes = (size_t)T * 16;  // one plane row range [T][8 halfs] of the q / k images
+  const char* cbase = reinterpret_cast<const char*>(wave >= 2 ? qi + q0 : ki) + (size_t)(4 * (wave & 1)) * rowbytes;
+  const unsigned c_tile_step = wave >= 2 ? 0u : (unsigned)FA_KT * 16u;  // k advances by 128 rows per key tile, q stays
+  // i-th piece (0 .. PC-1) of a chunk step / (0 .. PV-1) of a slab step: inside the main loop the pieces go out ONE AT A TIME between the MFMAs
+  // (a wave alone on its SIMD has no partner to cover a burst: eight back-to-back 1-KiB DMAs stall its instruction stream for hundreds of cycles
+  // while the CU's address path works through them -- all four waves bursting at the same point of the step)
+  auto issue_chunk_piece = [&](int kt, int u, int gslot, int i) {
+    const unsigned dst = lds0 + (unsigned)(gslot & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u) + (unsigned)wave * (PC * 1024u);
+    const char* b = cbase + (size_t)u * 8 * rowbytes + (size_t)kt * c_tile_step + (size_t)(i >> 1) * rowbytes;  // plane 4 (wave & 1) + i / 2
+    if (i & 1) fa_glds16i<1024>(b, voff, dst + (unsigned)(i & ~1) * 1024u);  // (the offset moves the LDS side too)
+    else fa_glds16i<0>(b, voff, dst + (unsigned)i * 1024u);
   };
-  auto issue_slab = [&](int kt, int sl, int gslot) {
-    const unsigned slot = lds0 + (unsigned)(gslot & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u);
-    const int kc = kt * (FA_KT / 32) + (sl >> 1), s = sl & 1;
+  auto issue_chunk = [&](int kt, int u, int gslot) {
 #pragma unroll
-    for (int i = 0; i < PV; ++i) {
-      const int p = wave * PV + i;  // [pp 4: hi h0, hi h1, lo h0, lo h1][C / 64 parts]
-      const int pp = p / (C / 64), part = p % (C / 64);
-      const int plane = (pp >> 1) * 4 + 2 * s + (pp & 1);
-      const float4* src = vi + ((size_t)(kc * 8 + plane) * C + part * 64);
-      fa_glds16(src, voff, slot + (unsigned)(pp * C + part * 64) * 16u);
+    for (int i = 0; i < PC; ++i) issue_chunk_piece(kt, u, gslot, i);
+  };
+  const char* vbase = reinterpret_cast<const char*>(vi) + (size_t)((wave >> 1) * 4 + (wave & 1)) * C * 16;  // plane (hi | lo) x lane half of this wave
+  auto issue_slab_piece = [&](int kt, int sl, int gslot, int i) {
+    static_assert(PV == 6, "C = 384: six 1-KiB pieces per plane");
+    const unsigned dst = lds0 + (unsigned)(gslot & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u) + (unsigned)wave * (C * 16u);
+    const char* b = vbase + ((size_t)(kt * (FA_KT / 32) + (sl >> 1)) * 8 + 2 * (sl & 1)) * C * 16;
+    switch (i) {
+      case 0: fa_glds16i<0>(b, voff, dst); break;
+      case 1: fa_glds16i<1024>(b, voff, dst); break;
+      case 2: fa_glds16i<2048>(b, voff, dst); break;
+      case 3: fa_glds16i<3072>(b, voff, dst); break;
+      case 4: fa_glds16i<0>(b + 4096, voff, dst + 4096u); break;
+      default: fa_glds16i<1024>(b + 4096, voff, dst + 4096u); break;
     }
   };
 
@@ -139,59 +160,108 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
   for (int c = 0; c < CB; ++c)
 #pragma unroll
     for (int e = 0; e < 16; ++e) O[c][e] = 0.f;
+  bool rescale = false;
+  float f_resc = 1.0f;
   float m_run = -INFINITY, l_run = 0.f;  // this lane's query (column r of the wave's 32), this lane half's 64 keys per tile for l
   const float s_scale = qk_inv[n] * k_inv[n];
   const float s2 = s_scale * 1.44269504088896340736f;  // scores in units of log2: p = 2^(s2 * acc - m)
 
-  static_assert(NCH >= FA_AHEAD && FA_AHEAD == 2 && (FA_SLOTS & (FA_SLOTS - 1)) == 0 && FA_SLOTS >= FA_AHEAD + 2, "prologue: the first two steps are chunk steps; ring arithmetic");
+  // ---- fragment registers, loaded ONE UNIT AHEAD of their MFMAs (a unit = one 16-deep k-step: 12 MFMAs of q k^T, or one 16-key slab of P v).
+  // One wave per SIMD has no partner to cover an LDS round trip, so every fragment is requested while the previous unit's MFMAs run -- across
+  // the step boundary too: the DMA runs three steps ahead and a step's data is confirmed one whole step before its first read.
+  constexpr int NQK = 2 * NCH;            // q k^T units per key tile
+  constexpr int NUNIT = NQK + NSL;
+  constexpr int VB = 4;                   // v^T fragment ring (channel blocks in flight)
+  static_assert(CB % VB == 0, "the ring runs on from one slab into the next");
+  F4H8 kh[2][4], kl[2][4], qh[2], ql[2], vh[VB], vl[VB];
+  auto slot_ptr = [&](int gstep) {
+    unsigned slot_b = (unsigned)(gstep & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u);
+    asm volatile("" : "+s"(slot_b));  // (opaque: one address register per operand kind + immediate offsets, nothing hoisted per slot)
+    return reinterpret_cast<const char*>(lds) + slot_b;
+  };
+  auto ld = [&](const char* slb, unsigned lane_part, int imm) { return *reinterpret_cast<const float4*>(slb + lane_part + imm); };
+  // q k^T unit (chunk u, k-step s) of the step at `slb` -> buffer `buf`
+  auto load_qk = [&](const char* slb, int s, int buf) {
+    qh[buf].f4 = ld(slb, lp_q, (1024 + 2 * s * 128) * 16);
+    if (TERMS == 3) ql[buf].f4 = ld(slb, lp_q, (1024 + (4 + 2 * s) * 128) * 16);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      kh[buf][b].f4 = ld(slb, lp_k, (2 * s * 128 + b * 32) * 16);
+      if (TERMS == 3) kl[buf][b].f4 = ld(slb, lp_k, ((4 + 2 * s) * 128 + b * 32) * 16);
+    }
+  };
+  auto load_v = [&](const char* slb, int c) {
+    vh[c % VB].f4 = ld(slb, lp_v, c * 32 * 16);
+    if (TERMS == 3) vl[c % VB].f4 = ld(slb, lp_v, (2 * C + c * 32) * 16);
+  };
+
+  static_assert(NCH >= FA_AHEAD && FA_AHEAD == 3 && (FA_SLOTS & (FA_SLOTS - 1)) == 0 && FA_SLOTS >= FA_AHEAD + 1, "prologue: the first three steps are chunk steps; ring arithmetic");
   issue_chunk(0, 0, 0);
   issue_chunk(0, 1, 1);
-  fa_wait_vmcnt<PC>();  // step 0 landed (step 1's pieces may still be in flight)
+  issue_chunk(0, 2, 2);
+  fa_wait_vmcnt<PC>();  // steps 0 and 1 landed (step 2's pieces may still be in flight)
   __builtin_amdgcn_s_barrier();
+  load_qk(slot_ptr(0), 0, 0);
 
-  int g = 0;
+  int g = 0;  // DMA step index (ring slot = g & 3)
   for (int kt = 0; kt < ntiles; ++kt) {
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) S[b][e] = 0.f;
-    fa_static_for(std::make_integer_sequence<int, NSTEP>{}, [&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      constexpr int u2 = (u + FA_AHEAD) % NSTEP;  // the step whose DMA goes out now (beyond the last tile: the first tile again -- a harmless re-read
-      {                                           // into a slot nobody reads any more)
-        int kt2 = kt + (u + FA_AHEAD >= NSTEP ? 1 : 0);
-        if (kt2 == ntiles) kt2 = 0;
-        if constexpr (u2 < NCH) issue_chunk(kt2, u2, g + FA_AHEAD); else issue_slab(kt2, u2 - NCH, g + FA_AHEAD);
-      }
-      // this step's slot as a running byte offset the compiler cannot see through: ONE address register per operand kind (+ immediate offsets)
-      // instead of a loop-invariant register per (slot, plane) pair beyond ds_read's 16-bit offset field -- those cost 14 spilled VGPRs whose
-      // reloads drained the DMA prefetch six times per key tile
-      unsigned slot_b = (unsigned)(g & (FA_SLOTS - 1)) * (FA_SLOT_F4 * 16u);
-      asm volatile("" : "+s"(slot_b));
-      const char* slb = reinterpret_cast<const char*>(lds) + slot_b;
-      auto ld = [&](unsigned lane_part, int imm) { return *reinterpret_cast<const float4*>(slb + lane_part + imm); };
-      if constexpr (u < NCH) {
-        // ---- S^T += k_chunk q_chunk^T : A = k rows (keys), B = q columns (queries)
+    fa_static_for(std::make_integer_sequence<int, NUNIT>{}, [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr bool is_qk = q < NQK;
+      constexpr int u = is_qk ? q / 2 : NCH + (q - NQK);           // DMA step of this unit inside the key tile
+      constexpr bool first_of_step = is_qk ? (q % 2 == 0) : true;
+      constexpr bool last_of_step = is_qk ? (q % 2 == 1) : true;
+      constexpr int u3 = (u + FA_AHEAD) % NSTEP;                    // the step whose DMA goes out at the top of this one
+      int kt3 = kt + (u + FA_AHEAD >= NSTEP ? 1 : 0);  // (beyond the last tile: the first tile again -- a harmless re-read into a slot nobody reads any more)
+      if (kt3 == ntiles) kt3 = 0;
+      // i-th DMA piece of step g + 3 (this step's share: a chunk step spreads its PC / PV pieces over its two units)
+      auto dma = [&](int i) {
+        if constexpr (u3 < NCH) issue_chunk_piece(kt3, u3, g + FA_AHEAD, i); else issue_slab_piece(kt3, u3 - NCH, g + FA_AHEAD, i);
+      };
+      constexpr int NP3 = u3 < NCH ? PC : PV;  // pieces of step g + 3
+      // ---- request the NEXT unit's fragments (its step is already confirmed), then run this unit's MFMAs
+      constexpr int qn = (q + 1) % NUNIT;
+      constexpr bool n_qk = qn < NQK;
+      const char* slb_n = slot_ptr(g + (last_of_step ? 1 : 0));
+      auto preload_next = [&]() {  // (a slab unit followed by another slab unit keeps its ring going instead: see below)
+        if constexpr (n_qk) {
+          load_qk(slb_n, qn % 2, qn % 2);
+        } else if constexpr (is_qk) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          F4H8 qh, ql;
-          qh.f4 = ld(lp_q, (1024 + 2 * s * 128) * 16);
-          if (TERMS == 3) ql.f4 = ld(lp_q, (1024 + (4 + 2 * s) * 128) * 16);
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            F4H8 kh, kl;
-            kh.f4 = ld(lp_k, (2 * s * 128 + b * 32) * 16);
-            if (TERMS == 3) {
-              kl.f4 = ld(lp_k, ((4 + 2 * s) * 128 + b * 32) * 16);
-              S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl.h8, qh.h8, S[b], 0, 0, 0);
-              S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh.h8, ql.h8, S[b], 0, 0, 0);
-            }
-            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh.h8, qh.h8, S[b], 0, 0, 0);
-          }
+          for (int c = 0; c < VB; ++c) load_v(slb_n, c);
         }
-        if constexpr (u == NCH - 1) {
+      };
+      // (the last q k^T unit of a tile requests the first slab's fragments AFTER its softmax: the rare rescale of O^T wants the VGPRs -- with the
+      // fragments live across it the register allocator spilled three blocks of O^T to scratch at every key tile)
+      if constexpr (q != NQK - 1) preload_next();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (is_qk) {
+        // ---- S^T += k q^T over 16 channels: A = k rows (keys), B = q columns (queries)
+        constexpr int buf = q % 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (TERMS == 3) {
+            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[buf][b].h8, qh[buf].h8, S[b], 0, 0, 0);
+            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[buf][b].h8, ql[buf].h8, S[b], 0, 0, 0);
+          }
+          S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[buf][b].h8, qh[buf].h8, S[b], 0, 0, 0);
+          // this unit's half of the step's DMA pieces, one behind each key block's MFMAs
+          constexpr int half = q % 2;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = half * (NP3 / 2) + b * (NP3 / 2) / 4; i < half * (NP3 / 2) + (b + 1) * (NP3 / 2) / 4; ++i) dma(i);
+          if (half == 1 && b == 3)
+#pragma unroll
+            for (int i = 2 * (NP3 / 2); i < NP3; ++i) dma(i);  // (odd piece counts)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (q == NQK - 1) {
           // ---- online softmax of the tile, in registers: this lane's query, 64 of the tile's 128 keys per lane half.  The reference maximum
-          // m_run is raised (and O^T rescaled: 3 x 192 register moves through the VGPRs) only when the tile's maximum exceeds it by more than
+          // m_run is raised (and O^T rescaled, in the first slab unit below: 3 x 192 register moves through the VGPRs) only when the tile's maximum exceeds it by more than
           // FA_TAU (in log2 units): below that the probabilities are simply 2^(s - m_run) <= 2^FA_TAU -- the final O / l does not depend on
           // which reference was used, and the fp16 staging of the probabilities (x FA_PSCALE) has the head-room for it
           float mt = S[0][0];
@@ -202,28 +272,25 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
           mt *= s2;  // (s2 > 0)
           mt = fmaxf(mt, __shfl_xor(mt, 32));
           const bool raise = mt > m_run + FA_TAU;
-          if (__any(raise)) {  // (wave-uniform branch; lanes that do not raise rescale by 1)
+          rescale = __any(raise);  // (wave-uniform; lanes that do not raise rescale by 1)
+          f_resc = 1.0f;
+          if (rescale) {
             const float m_new = raise ? mt : m_run;
-            const float f = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 2^(-inf) = 0
+            f_resc = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 2^(-inf) = 0
             m_run = m_new;
-            l_run *= f;
-#pragma unroll
-            for (int c = 0; c < CB; ++c) {
-#pragma unroll
-              for (int e = 0; e < 16; ++e) O[c][e] *= f;
-              __builtin_amdgcn_sched_barrier(0);  // one block at a time through the VGPRs (the scheduler otherwise hoists all 192 reads)
-            }
+            l_run *= f_resc;
           }
-          // The raw scores stay in the S^T accumulators: every slab step below turns the eight it needs into probabilities (exp, row-sum
+          // The raw scores stay in the S^T accumulators: every slab unit below turns the eight it needs into probabilities (exp, row-sum
           // share, fp16 hi / lo split) between its MFMAs.  The empty asm pins them to the accumulator file here -- without it the compiler keeps
           // the 64 values it has just read for the maximum (and then the 64 probabilities) in VGPRs through the whole P v phase: 128 of the
           // 256 architectural registers, and spills around them.
 #pragma unroll
           for (int b = 0; b < 4; ++b) asm volatile("" : "+a"(S[b]));
+          preload_next();
         }
       } else {
         // ---- O^T += v^T_slab P^T_slab : A = v^T rows (channels), B = the probabilities of key block kb, k-step s
-        constexpr int slab = u - NCH, kb = slab >> 1, s = slab & 1;
+        constexpr int slab = q - NQK, kb = slab >> 1, s = slab & 1;
         F4H8 ph, pl;  // registers 8s .. 8s+7 of key block kb: the B fragment of this k-step (keys in accumulator order, as v^T is packed)
         float psum = 0.f;
 #pragma unroll
@@ -235,24 +302,51 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
           ph.h8[j] = hi;
           if (TERMS == 3) pl.h8[j] = (_Float16)(ps - (float)hi);
         }
+        l_run += psum;
+        const char* slb = slot_ptr(g);
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
-          F4H8 vh, vl;
-          vh.f4 = ld(lp_v, c * 32 * 16);
-          if (TERMS == 3) {
-            vl.f4 = ld(lp_v, (2 * C + c * 32) * 16);
-            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.h8, ph.h8, O[c], 0, 0, 0);
-            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.h8, pl.h8, O[c], 0, 0, 0);
+          if constexpr (slab == 0) {
+            // the (rare) rescale of O^T by 2^(m_old - m_new) rides in the tile's first slab unit, one block at a time just ahead of the block's
+            // MFMAs: as one 192-register pass behind the softmax it made the register allocator spill three blocks of O^T at every key tile
+            if (rescale) {
+              // (the pins make the block a fresh accumulator-file value on both sides: without the first the allocator treats the tile-start value
+              // of the last three blocks as a VGPR-class live range across the whole q k^T phase and parks it in scratch at every key tile)
+              asm volatile("" : "+a"(O[c]));
+#pragma unroll
+              for (int e = 0; e < 16; ++e) O[c][e] *= f_resc;
+              asm volatile("" : "+a"(O[c]));
+            }
           }
-          O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.h8, ph.h8, O[c], 0, 0, 0);
+          if (TERMS == 3) {
+            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[c % VB].h8, ph.h8, O[c], 0, 0, 0);
+            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[c % VB].h8, pl.h8, O[c], 0, 0, 0);
+          }
+          O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[c % VB].h8, ph.h8, O[c], 0, 0, 0);
+          {  // the step's DMA pieces, spread over the channel blocks
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = c * NP3 / CB; i < (c + 1) * NP3 / CB; ++i) dma(i);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // into the ring entry block c has just released: block c + VB of this slab, or -- the ring runs on -- block c + VB - CB of the next one
+          if (c + VB < CB) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_v(slb, c + VB);
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (!n_qk) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_v(slb_n, c + VB - CB);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-        l_run += psum;
       }
-      // the pieces of step g + 1 (issued one step ago) have landed for this wave; allowed in flight: the pieces of step g + 2 issued above
-      if constexpr (u2 < NCH) fa_wait_vmcnt<PC>(); else fa_wait_vmcnt<PV>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      ++g;
+      if constexpr (last_of_step) {
+        // everything up to the pieces of step g + 2 has landed for this wave; allowed in flight: the pieces of step g + 3 issued at the top of this step
+        if constexpr (u3 < NCH) fa_wait_vmcnt<PC>(); else fa_wait_vmcnt<PV>();
+        __builtin_amdgcn_s_barrier();
+        ++g;
+      }
     });
   }
   fa_wait_vmcnt<0>();  // drain the wrapped prefetches before the workgroup's LDS can be re-assigned
