@@ -102,7 +102,7 @@ def test_ancestral_1000_step_chain_vs_reference(dev, precision):
 def test_stress_weights_vs_reference(dev, name, cfg, kind, gain, precision):
     """gain 3: within the contract of the fp32 reference (which is itself within 3e-6 of fp64).  gain 10: the fp32 reference is 4e-6 ... 3e-2
     from the same network in fp64 (attention logits x 100: every fp32 evaluation is a different draw of that noise -- the exact-fp32 mode lands
-    at 2.4 x the reference's distance on IllNet 64x64): the HIP path must be no further from fp64 than 5 x the reference is, or inside the
+    at 2.4 x the reference's distance on IllNet 64x64, 5.8 x on ObsNet): the HIP path must be no further from fp64 than 10 x the reference is, or inside the
     contract; what the case guards is a split mode falling OUT of that band (a range or scaling failure under large gains)."""
     from drmnet_amd.unet import EncoderUNetModel, UNetModel
 
@@ -124,7 +124,7 @@ def test_stress_weights_vs_reference(dev, name, cfg, kind, gain, precision):
         if gain == 3:
             assert e32 < (NET_TOL[precision] if precision != "f16mx" else CONTRACT)
         else:
-            assert e64 < max(5 * r64, CONTRACT if precision == "f16mx" else 2e-5)  # (noise-level comparison: exact fp32 lands at 2.4 x r64 on IllNet 64x64)
+            assert e64 < max(10 * r64, CONTRACT if precision == "f16mx" else 2e-5)  # (noise-level comparison: exact fp32 lands at 2.4 x r64 on IllNet, 5.8 x on ObsNet 64x64)
     del m
     torch.cuda.empty_cache()
 
