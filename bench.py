@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--workload", default="drmnet_step", choices=["drmnet_step", "illnet", "refnet", "obsnet", "obsnet_ddim", "obsnet_ddim_chain", "estimate_chain"])
-    ap.add_argument("--precision", default="f16mx", choices=["fp32", "f16x3", "f16", "f16mx"],
+    ap.add_argument("--precision", default="f16mx", choices=["fp32", "f16x3", "f16", "f16mx", "bf16"],
                     help="conv arithmetic: f16mx (default) = fp32 operands split into fp16 hi+lo; hi*hi on the f16 MFMA, both cross terms of the "
                          "GroupNorm-fed 3x3 convs in one block-scaled fp8 MFMA (2.4e-5 .. 4e-5 rel-L2 per network against the reference, 1e-4 contract: "
                          "tests/test_gpu_f16mx.py); f16x3 = all three products on the f16 MFMA (~2e-6: passes the SAME tolerances as fp32, "
@@ -445,7 +445,7 @@ def secondary_pass(args, model, dev):
     x = synth.synth_refmaps(256, 128, 256, synth.SEED_INPUT).to(dev)
     xT = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
     chains = {}
-    for prec in ((acc, "f16x3", "f16") if acc != "f16x3" else ("f16x3", "f16")):
+    for prec in ((acc, "f16x3", "f16", "bf16") if acc != "f16x3" else ("f16x3", "f16", "bf16")):
         obs.set_precision(prec)
         smp = DDIMSampler(obs)
         smp.make_schedule(50, ddim_eta=1.0, verbose=False)
@@ -475,8 +475,9 @@ def secondary_pass(args, model, dev):
                                                      "of_schedule": 1000, "finite": bool(torch.isfinite(res["x"]).all().item()), "precision": acc}
     except Exception as e:  # noqa: BLE001
         out["obsnet_ancestral_ddpm_b32_3x128x256"] = {"error": f"{type(e).__name__}: {e}"}
-    chains["note"] = ("f16mx / f16x3 = the two accurate split modes (1e-4 contract; cross terms on the block-scaled fp8 MFMA / on the f16 MFMA); f16 = fp16 operands, fp32 accumulate: the reduced-precision mode standing in for "
-                      "configs[2]'s bf16 (more mantissa, guarded range; 5e-3 tolerance, tests/test_gpu_configs.py)")
+    chains["note"] = ("f16mx / f16x3 = the two accurate split modes (1e-4 contract; cross terms on the block-scaled fp8 MFMA / on the f16 MFMA); bf16 = configs[2] AS WRITTEN "
+                      "(bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate; 3e-2 tolerance, tests/test_gpu_bf16.py); f16 = the same kernels on fp16 operands "
+                      "(three more mantissa bits at the same speed; 5e-3 tolerance, tests/test_gpu_configs.py)")
     out["obsnet_ddim50_chain_b256_3x128x256"] = chains
     del x, xT
     torch.cuda.empty_cache()
@@ -659,7 +660,7 @@ def main():
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
             split = args.precision in ("f16x3", "f16mx")
             mx = args.precision == "f16mx"
-            plain = args.precision == "f16"  # reduced precision (BASELINE configs[2]); never the default
+            plain = args.precision in ("f16", "bf16")  # reduced precision (BASELINE configs[2]); never the default
             peak = F16_MFMA_PEAK_TFLOPS if (split or plain) else FP32_MFMA_PEAK_TFLOPS
             kname = ("conv_igemm_split_kernel<9,...> (fused GroupNorm+SiLU+conv3x3, fp16 hi/lo x3 v_mfma_f32_32x32x16_f16, fp32 accumulate; "
                      "achieved counts ALGORITHMIC FLOPs, the matrix cores execute 3x that)") if split else \
@@ -738,10 +739,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "f16x3": "f32-accurate split: f16 hi/lo x3 MFMA, fp32 acc", "f16": "f16 operands, fp32 acc (reduced precision)",
+                      "bf16": "bf16 operands, fp32 acc (reduced precision)",
                       "f16mx": "f32-accurate split: f16 hi*hi + e4m3 cross terms, fp32 acc"}[args.precision],
             "dtype_note": {"fp32": "v_mfma_f32_32x32x2_f32, exact fp32 products",
                            "f16x3": "every fp32 operand split into fp16 hi + lo, 3 MFMAs per product, fp32 accumulate: ~2e-6 rel-L2 against the reference (the fp32 tolerances)",
                            "f16": "REDUCED PRECISION, ~1e-3 rel-L2: not the headline configuration",
+                           "bf16": "REDUCED PRECISION (BASELINE configs[2] as written), ~1e-2 rel-L2: not the headline configuration",
                            "f16mx": "f16x3 with the GroupNorm-fed 3x3 convs on fp16 hi*hi + ONE block-scaled fp8 (e4m3) MFMA for both cross terms; emulated fp32 with ~15-bit "
                                     "products: 2.4e-5 .. 4.0e-5 rel-L2 per network against the reference at B = 1 .. 256, <= 5e-5 on the 150-step / 1000-step reference chains "
                                     "(1e-4 contract; tests/test_gpu_*.py run every BASELINE-shaped case in this mode); the f16x3 and exact-fp32 figures of the same run are "

@@ -78,7 +78,7 @@ int pack_for_ops(const float* w, float* dst, float* slot, float* scratch, int co
                  bool mx_site = false) {
   if (g_op_precision != PREC_FP32 && cinp % 32 == 0)
     return launch_pack_conv_weight_split(w, dst, slot, reinterpret_cast<unsigned*>(scratch), cout, cin, taps, coutp, cinp, s,
-                                         g_op_precision == PREC_F16MX && mx_site);
+                                         g_op_precision == PREC_F16MX && mx_site, g_op_precision == PREC_BF16);
   return launch_pack_conv_weight(w, dst, cout, cin, taps, coutp, cinp, s);
 }
 
@@ -399,16 +399,16 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
 
 int drm_unet_set_precision(drm_unet* net, int precision) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(net && (precision == PREC_FP32 || precision == PREC_F16X3 || precision == PREC_F16 || precision == PREC_F16MX),
-                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3), 2 (plain fp16 operands) or 3 (split fp16 with fp8 cross terms)");
+    DRM_REQUIRE(net && precision_valid(precision),
+                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3), 2 (plain fp16 operands), 3 (split fp16 with fp8 cross terms) or 4 (plain bf16 operands)");
     net->net.precision = precision;
     return DRM_OK;
   });
 }
 int drm_set_op_precision(int precision) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(precision == PREC_FP32 || precision == PREC_F16X3 || precision == PREC_F16 || precision == PREC_F16MX,
-                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3), 2 (plain fp16 operands) or 3 (split fp16 with fp8 cross terms)");
+    DRM_REQUIRE(precision_valid(precision),
+                "precision must be 0 (fp32 MFMA), 1 (split fp16 x3), 2 (plain fp16 operands), 3 (split fp16 with fp8 cross terms) or 4 (plain bf16 operands)");
     g_op_precision = precision;
     return DRM_OK;
   });

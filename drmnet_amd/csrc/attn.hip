@@ -121,10 +121,20 @@ __global__ __launch_bounds__(256) void bgemm64_kernel(const float* __restrict__ 
 // (~2^-22 relative per product).  A is multiplied by a_scale (a power of two) before the split -- softmax probabilities
 // would otherwise sit in fp16's subnormal range -- and alpha carries the inverse.  Needs K % 32 == 0.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
 union AF4H8 {
   float4 f4;
   f16x8 h8;
+  abf16x8 b8;
 };
+// bf16 operands (DRM_PREC_BF16): round to nearest even, no range clamp (fp32's exponent); the lo image is unused
+__device__ __forceinline__ void round8_bf16(const float (&v)[8], float scale, float4& hi, float4& lo) {
+  AF4H8 h;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) h.b8[k] = (__bf16)(v[k] * scale);
+  hi = h.f4;
+  lo = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, float4& hi, float4& lo) {
   AF4H8 h, l;
 #pragma unroll
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
         const float4 x = p[0], y = p[1];
         v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
       }
-      split8(v, a_scale, As[oct * 64 + row], As[(4 + oct) * 64 + row]);
+      if (TERMS == 4) round8_bf16(v, a_scale, As[oct * 64 + row], As[(4 + oct) * 64 + row]);
+      else split8(v, a_scale, As[oct * 64 + row], As[(4 + oct) * 64 + row]);
     }
     if (BT) {
       const int col = tid >> 2, oct = tid & 3;
@@ -175,7 +186,8 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
         const float4 x = p[0], y = p[1];
         v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
       }
-      split8(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+      if (TERMS == 4) round8_bf16(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+      else split8(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
     } else {
       const int oct = tid >> 6, col = tid & 63;
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -184,7 +196,8 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = p[(size_t)j * ldb];
       }
-      split8(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+      if (TERMS == 4) round8_bf16(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+      else split8(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
     }
     __syncthreads();
 #pragma unroll
@@ -199,7 +212,8 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h8, bh.h8, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bl.h8, acc, 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bh.h8, acc, 0, 0, 0);
+      if (TERMS == 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.b8, bh.b8, acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bh.h8, acc, 0, 0, 0);
     }
     __syncthreads();
   }
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_scales_kernel(const double2* __restr
 // grid (blocks, N), block 256.
 template <bool ROWS>
 __global__ __launch_bounds__(256) void pack_attn_weight_kernel(const float* __restrict__ src, long long img_stride, int ld,
-                                                               const float* __restrict__ scale, float4* __restrict__ dst, int Cout, int Cin) {
+                                                               const float* __restrict__ scale, float4* __restrict__ dst, int Cout, int Cin, int bf16) {
   const int n = blockIdx.y;
   const float sc = scale[n];
   const float* sp = src + (size_t)n * img_stride;
@@ -335,12 +349,16 @@ __global__ __launch_bounds__(256) void pack_attn_weight_kernel(const float* __re
       for (int j = 0; j < 8; ++j) v[j] = sp[(size_t)(ci0 + j) * ld + co];
     }
     AF4H8 hi, lo;
+    if (bf16) {
+      round8_bf16(v, sc, hi.f4, lo.f4);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float c = __builtin_amdgcn_fmed3f(v[j] * sc, -65504.0f, 65504.0f);
-      const _Float16 hh = (_Float16)c;
-      hi.h8[j] = hh;
-      lo.h8[j] = (_Float16)(c - (float)hh);
+      for (int j = 0; j < 8; ++j) {
+        const float c = __builtin_amdgcn_fmed3f(v[j] * sc, -65504.0f, 65504.0f);
+        const _Float16 hh = (_Float16)c;
+        hi.h8[j] = hh;
+        lo.h8[j] = (_Float16)(c - (float)hh);
+      }
     }
     dp[((size_t)q * 8 + seg) * Cout + co] = hi.f4;
     dp[((size_t)q * 8 + 4 + seg) * Cout + co] = lo.f4;
@@ -428,9 +446,9 @@ void launch_attn_scales(const double2* mom, int N, int C, int T, float alpha, fl
   hipLaunchKernelGGL(attn_scales_kernel, dim3(N), dim3(256), 0, s, mom, C, T, alpha, q_tab, p_tab, zero_tab, qk_inv, k_scale, k_inv, pv_inv, v_scale, v_inv,
                      o_tab, q_scale);
 }
-int launch_pack_attn_rows(const float* src, long long img_stride, int ld, const float* scale, float* dst, int rows, int cin, int N, hipStream_t s) {
+int launch_pack_attn_rows(const float* src, long long img_stride, int ld, const float* scale, float* dst, int rows, int cin, int N, hipStream_t s, bool bf16) {
   const unsigned pb = (unsigned)std::min<size_t>(((size_t)rows * cin / 8 + 255) / 256, 4096);
-  hipLaunchKernelGGL(pack_attn_weight_kernel<true>, dim3(pb, N), dim3(256), 0, s, src, img_stride, ld, scale, reinterpret_cast<float4*>(dst), rows, cin);
+  hipLaunchKernelGGL(pack_attn_weight_kernel<true>, dim3(pb, N), dim3(256), 0, s, src, img_stride, ld, scale, reinterpret_cast<float4*>(dst), rows, cin, bf16 ? 1 : 0);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }
@@ -463,10 +481,10 @@ int launch_attention_conv(const float* qkv, const double2* qkv_mom, float* score
   }
   const unsigned pb = (unsigned)std::min<size_t>(((size_t)T * C / 8 + 255) / 256, 4096);
   hipLaunchKernelGGL(pack_attn_weight_kernel<true>, dim3(pb, N), dim3(256), 0, s, qkv + C, (long long)T * 3 * C, 3 * C, k_scale,
-                     reinterpret_cast<float4*>(wk), T, C);
+                     reinterpret_cast<float4*>(wk), T, C, terms == 4 ? 1 : 0);
   DRM_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(pack_attn_weight_kernel<false>, dim3(pb, N), dim3(256), 0, s, qkv + 2 * C, (long long)T * 3 * C, 3 * C, v_scale,
-                     reinterpret_cast<float4*>(wv), C, T);
+                     reinterpret_cast<float4*>(wv), C, T, terms == 4 ? 1 : 0);
   DRM_HIP_CHECK(hipGetLastError());
   const int NB = attention_group(N, T);
   for (int n0 = 0; n0 < N; n0 += NB) {  // one pass per image group (scores = the group's [nb, T, T] buffer)
@@ -502,7 +520,9 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
     const int nb = std::min(NB, N - n0);
     const float* qg = qkv + (size_t)n0 * sq;
     float* og = out + (size_t)n0 * T * C;
-    if (split && terms == 1)
+    if (split && terms == 4)
+      hipLaunchKernelGGL((bgemm64s_kernel<true, 4>), dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha, 1.0f);
+    else if (split && terms == 1)
       hipLaunchKernelGGL((bgemm64s_kernel<true, 1>), dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha, 1.0f);
     else if (split)
       hipLaunchKernelGGL((bgemm64s_kernel<true, 3>), dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha, 1.0f);
@@ -510,7 +530,10 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
       hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha);
     DRM_HIP_CHECK(hipGetLastError());
     DRM_TRY(launch_softmax_rows(scores, (long long)nb * T, T, s));
-    if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
+    if (split && terms == 4)
+      hipLaunchKernelGGL((bgemm64s_kernel<false, 4>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
+                         (long long)T * T, sq, (long long)T * C, 1.0f, 1.0f);
+    else if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
       hipLaunchKernelGGL((bgemm64s_kernel<false, 1>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
                          (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
     else if (split)

@@ -35,10 +35,18 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union F4H8 {
   float4 f4;
   f16x8 h8;
+  bf16x8 b8;
 };
+// one 32x32x16 product on the operand type of the mode (TERMS = 4: bf16, else fp16)
+template <int TERMS>
+__device__ __forceinline__ f32x16 fa_mma(const F4H8& a, const F4H8& b, f32x16 c) {
+  if constexpr (TERMS == 4) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b8, b.b8, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h8, b.h8, c, 0, 0, 0);
+}
 
 constexpr int FA_QT = 128;          // queries per workgroup: 4 waves x 32
 constexpr int FA_KT = 128;          // keys per tile
@@ -245,10 +253,10 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           if (TERMS == 3) {
-            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[buf][b].h8, qh[buf].h8, S[b], 0, 0, 0);
-            S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[buf][b].h8, ql[buf].h8, S[b], 0, 0, 0);
+            S[b] = fa_mma<TERMS>(kl[buf][b], qh[buf], S[b]);
+            S[b] = fa_mma<TERMS>(kh[buf][b], ql[buf], S[b]);
           }
-          S[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[buf][b].h8, qh[buf].h8, S[b], 0, 0, 0);
+          S[b] = fa_mma<TERMS>(kh[buf][b], qh[buf], S[b]);
           // this unit's half of the step's DMA pieces, one behind each key block's MFMAs
           constexpr int half = q % 2;
           __builtin_amdgcn_sched_barrier(0);
@@ -298,9 +306,13 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
           const float pr = __builtin_amdgcn_exp2f(S[kb][8 * s + j] * s2 - m_run);
           psum += pr;
           const float ps = pr * FA_PSCALE;
-          const _Float16 hi = (_Float16)ps;
-          ph.h8[j] = hi;
-          if (TERMS == 3) pl.h8[j] = (_Float16)(ps - (float)hi);
+          if constexpr (TERMS == 4) {
+            ph.b8[j] = (__bf16)ps;
+          } else {
+            const _Float16 hi = (_Float16)ps;
+            ph.h8[j] = hi;
+            if (TERMS == 3) pl.h8[j] = (_Float16)(ps - (float)hi);
+          }
         }
         l_run += psum;
         const char* slb = slot_ptr(g);
@@ -319,10 +331,10 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
             }
           }
           if (TERMS == 3) {
-            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[c % VB].h8, ph.h8, O[c], 0, 0, 0);
-            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[c % VB].h8, pl.h8, O[c], 0, 0, 0);
+            O[c] = fa_mma<TERMS>(vl[c % VB], ph, O[c]);
+            O[c] = fa_mma<TERMS>(vh[c % VB], pl, O[c]);
           }
-          O[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[c % VB].h8, ph.h8, O[c], 0, 0, 0);
+          O[c] = fa_mma<TERMS>(vh[c % VB], ph, O[c]);
           {  // the step's DMA pieces, spread over the channel blocks
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
 // which the S^T accumulator registers 8s .. 8s+7 of lane half h enumerate their keys.  A thread produces one hi + one lo entry (8 keys of one
 // channel); adjacent lanes take adjacent channels: every load is a coalesced row segment.   grid (blocks, N), block 256.
 __global__ __launch_bounds__(256) void pack_attn_v_perm_kernel(const float* __restrict__ src, long long img_stride, int ld, const float* __restrict__ scale,
-                                                               float4* __restrict__ dst, int C, int T) {
+                                                               float4* __restrict__ dst, int C, int T, int bf16) {
   const int n = blockIdx.y;
   const float sc = scale[n];
   const float* sp = src + (size_t)n * img_stride;
@@ -382,6 +394,11 @@ __global__ __launch_bounds__(256) void pack_attn_v_perm_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int key = 32 * kc + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+      if (bf16) {
+        hi.b8[j] = (__bf16)(sp[(size_t)key * ld + c] * sc);
+        lo.h8[j] = (_Float16)0.f;
+        continue;
+      }
       const float v = __builtin_amdgcn_fmed3f(sp[(size_t)key * ld + c] * sc, -65504.0f, 65504.0f);
       const _Float16 x = (_Float16)v;
       hi.h8[j] = x;
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(256) void pack_attn_v_perm_kernel(const float* __re
   }
 }
 
-bool attention_flash_applicable(int T, int C, int terms) { return (terms == 3 || terms == 1) && C == 384 && T % FA_KT == 0 && T >= 1024; }
+bool attention_flash_applicable(int T, int C, int terms) { return (terms == 3 || terms == 1 || terms == 4) && C == 384 && T % FA_KT == 0 && T >= 1024; }
 
 size_t attention_flash_workspace_floats(int N, int T, int C) {
   const size_t Z = (size_t)(C > T ? C : T);
@@ -402,7 +419,7 @@ size_t attention_flash_workspace_floats(int N, int T, int C) {
 // (attn.hip)
 void launch_attn_scales(const double2* mom, int N, int C, int T, float alpha, float* q_tab, float* p_tab, float* zero_tab, float* qk_inv, float* k_scale,
                         float* k_inv, float* pv_inv, float* v_scale, float* v_inv, float* o_tab, float* q_scale, hipStream_t s);
-int launch_pack_attn_rows(const float* src, long long img_stride, int ld, const float* scale, float* dst, int rows, int cin, int N, hipStream_t s);
+int launch_pack_attn_rows(const float* src, long long img_stride, int ld, const float* scale, float* dst, int rows, int cin, int N, hipStream_t s, bool bf16);
 
 // qkv [N][T][3C] (+ its fused per-channel statistics), out [N][T][C], ws: attention_flash_workspace_floats.
 // proj_guard (optional): receives the (scale, shift, inverse) tables that guard proj_out's read of `out`, as launch_attention_conv does
@@ -429,10 +446,10 @@ int launch_attention_flash(const float* qkv, const double2* qkv_mom, float* out,
     proj_guard->in_inv = v_inv;
   }
   const long long sq = (long long)T * 3 * C;
-  DRM_TRY(launch_pack_attn_rows(qkv, sq, 3 * C, q_scale, wq, T, C, N, s));
-  DRM_TRY(launch_pack_attn_rows(qkv + C, sq, 3 * C, k_scale, wk, T, C, N, s));
+  DRM_TRY(launch_pack_attn_rows(qkv, sq, 3 * C, q_scale, wq, T, C, N, s, terms == 4));
+  DRM_TRY(launch_pack_attn_rows(qkv + C, sq, 3 * C, k_scale, wk, T, C, N, s, terms == 4));
   const unsigned pb = (unsigned)std::min<size_t>(((size_t)T * C / 8 + 255) / 256, 4096);
-  hipLaunchKernelGGL(pack_attn_v_perm_kernel, dim3(pb, N), dim3(256), 0, s, qkv + 2 * C, sq, 3 * C, v_scale, reinterpret_cast<float4*>(wv), C, T);
+  hipLaunchKernelGGL(pack_attn_v_perm_kernel, dim3(pb, N), dim3(256), 0, s, qkv + 2 * C, sq, 3 * C, v_scale, reinterpret_cast<float4*>(wv), C, T, terms == 4 ? 1 : 0);
   DRM_HIP_CHECK(hipGetLastError());
   const size_t lds_bytes = (size_t)FA_SLOTS * FA_SLOT_F4 * sizeof(float4);
   const DeviceInfo* di = device_info();
@@ -448,6 +465,7 @@ int launch_attention_flash(const float* qkv, const double2* qkv_mom, float* out,
     DRM_HIP_CHECK(hipGetLastError());
     return DRM_OK;
   };
+  if (terms == 4) return go(attn_flash_kernel<384, 4>);
   if (terms == 1) return go(attn_flash_kernel<384, 1>);
   return go(attn_flash_kernel<384, 3>);
 }

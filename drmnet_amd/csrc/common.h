@@ -81,7 +81,7 @@ struct ConvArgs {
   size_t split_stride = 0;             // floats between the split-K slabs (0 unless ksplit > 1)
   float* split_ws = nullptr;           // fused split-K: slab workspace ([ksplit] slabs of split_stride floats); the workgroup that arrives LAST at an output tile
   unsigned* tile_ticket = nullptr;     // (arrival counter per output tile, zero before the launch) sums the slabs in slab order and runs the full epilogue into `out`
-  int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 2 = fp16 hi*hi + fp8 cross terms, 1 = plain fp16 operands
+  int terms = 3;                       // split kernels: 3 = fp16 hi/lo (fp32 accuracy), 2 = fp16 hi*hi + fp8 cross terms, 1 = plain fp16 operands, 4 = plain bf16 operands
   int mx_site = 0;                     // PREC_F16MX: this launch is one of the 3x3 convs whose weights carry the f16mx image
 #ifdef DRM_S2_STAMP
   unsigned* stamp_out = nullptr;       // diagnostic build: [8 waves][120][2] (id, s_memtime low word) of one workgroup
@@ -108,9 +108,11 @@ bool conv_split_fuses_stats();  // true when the active split kernel accumulates
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);
 // mx: the f16mx image (fp16 hi planes + e4m3 planes of hi and lo) for the 3x3 convs that run with ConvArgs::terms == 2
 int launch_pack_conv_weight_split(const float* w, float* packed, float* scales, unsigned* scratch, int Cout, int Cin, int taps, int CoutP,
-                                  int CinP, hipStream_t s, bool mx = false);
+                                  int CinP, hipStream_t s, bool mx = false, bool bf16 = false);
 // PREC_F16MX: PREC_F16X3 with the GroupNorm-fed 3x3 convs on fp16 hi*hi + one block-scaled fp8 MFMA for both cross terms (~4e-5 per network)
-enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2, PREC_F16MX = 3 };
+// PREC_BF16: bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16): BASELINE configs[2] as written; reduced precision like PREC_F16
+enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2, PREC_F16MX = 3, PREC_BF16 = 4 };
+inline bool precision_valid(int p) { return p >= PREC_FP32 && p <= PREC_BF16; }
 // repack PyTorch conv weight [Cout][Cin][kh][kw] -> [taps][CinP/4][CoutP][4] (zero padded)
 int launch_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int taps, int CoutP, int CinP, hipStream_t s);
 size_t packed_conv_weight_floats(int taps, int CoutP, int CinP);

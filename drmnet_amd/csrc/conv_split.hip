@@ -62,7 +62,7 @@ __global__ void split_scale_kernel(const unsigned* __restrict__ absmax_bits, flo
 }
 
 __global__ void pack_conv_weight_split_kernel(const float* __restrict__ w, _Float16* __restrict__ p, const float* __restrict__ scales, int Cout,
-                                              int Cin, int taps, int CoutP, int CinP) {
+                                              int Cin, int taps, int CoutP, int CinP, int bf16 /* hi plane as bf16 bits (DRM_PREC_BF16), lo plane zero */) {
   const int nchunks = CinP / 32;
   const size_t total = (size_t)taps * nchunks * 2 * 2 * 2 * CoutP * 8;
   const float scale = scales[0];
@@ -78,6 +78,11 @@ __global__ void pack_conv_weight_split_kernel(const float* __restrict__ w, _Floa
     const int ci = 32 * q + 16 * s + 8 * hh + j;
     float v = 0.f;
     if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * taps + tap] * scale;
+    if (bf16) {
+      const __bf16 b = (__bf16)v;
+      p[i] = hl ? (_Float16)0.f : __builtin_bit_cast(_Float16, b);
+      continue;
+    }
     const _Float16 hi = (_Float16)v;
     p[i] = hl ? (_Float16)(v - (float)hi) : hi;
   }
@@ -117,7 +122,7 @@ size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP) {
 }
 
 int launch_pack_conv_weight_split(const float* w, float* packed, float* scales /*[2] device*/, unsigned* scratch /*1 uint device*/, int Cout,
-                                  int Cin, int taps, int CoutP, int CinP, hipStream_t s, bool mx) {
+                                  int Cin, int taps, int CoutP, int CinP, hipStream_t s, bool mx, bool bf16) {
   DRM_REQUIRE(CinP % 32 == 0 && CoutP >= Cout && CinP >= Cin, "pack_conv_weight_split padding");
   const size_t n = (size_t)Cout * Cin * taps;
   DRM_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(unsigned), s));
@@ -127,7 +132,7 @@ int launch_pack_conv_weight_split(const float* w, float* packed, float* scales /
   DRM_HIP_CHECK(hipGetLastError());
   const size_t total = (size_t)taps * CoutP * CinP * 2;
   hipLaunchKernelGGL(pack_conv_weight_split_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w,
-                     reinterpret_cast<_Float16*>(packed), scales, Cout, Cin, taps, CoutP, CinP);
+                     reinterpret_cast<_Float16*>(packed), scales, Cout, Cin, taps, CoutP, CinP, bf16 ? 1 : 0);
   DRM_HIP_CHECK(hipGetLastError());
   if (mx) {  // (overwrites the lo planes the launch above filled)
     const size_t bytes = (size_t)taps * CoutP * CinP * 2;

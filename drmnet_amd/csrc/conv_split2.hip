@@ -18,7 +18,8 @@
 // All vector-memory operations a wave issues are unconditional (clamped addresses, zero-filled afterwards) so the
 // vmcnt bookkeeping below is exact and identical for every wave.
 // Arithmetic (TERMS): 3 = the three-product fp16 split above; 2 = hi*hi on the f16 MFMA + both cross terms in one block-scaled fp8 MFMA
-// ("f16mx", the GroupNorm-fed 3x3 convs); 1 = plain fp16 operands; 0 = exact fp32 (v_mfma_f32_32x32x2_f32) -- all on this one pipeline.
+// ("f16mx", the GroupNorm-fed 3x3 convs); 1 = plain fp16 operands; 4 = plain bf16 operands (v_mfma_f32_32x32x16_bf16: BASELINE configs[2] as
+// written); 0 = exact fp32 (v_mfma_f32_32x32x2_f32) -- all on this one pipeline.
 // Split-K (deep, small maps): every split writes its own slab; SK instantiations finish the tile inside the launch (last-arriving workgroup).
 #include <algorithm>
 #include <atomic>
@@ -56,6 +57,7 @@ namespace drm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
@@ -112,7 +114,8 @@ struct S2Cfg {
   static constexpr int A1_F4 = 8 * HPS;                      // one activation tile image
   static constexpr int A_F4 = A_COPIES * A1_F4;  // 1x1: double-buffered (a new tile every step)
   static constexpr int B_F4 = 8 * BN;                            // LDS image of one tap's weight tile (hi and lo planes)
-  static constexpr int B_DMA_F4 = (TERMS == 1 ? 4 : 8) * BN;      // what is fetched: the single-product mode needs the hi plane only
+  static constexpr bool ONE = (TERMS == 1 || TERMS == 4);       // single-product modes: fp16 / bf16 operands, the hi plane only
+  static constexpr int B_DMA_F4 = (ONE ? 4 : 8) * BN;            // what is fetched: the single-product modes need the hi plane only
   static constexpr int B_PER = (B_DMA_F4 + NTHR - 1) / NTHR;      // LDS-DMA instructions per (issuing) wave per weight tile
   static constexpr int NG = TAPS / TPS;      // pipeline steps ("groups" of TPS taps) per 32-channel chunk
   static constexpr int G_PER = TPS * B_PER;  // LDS-DMA instructions per wave per group
@@ -137,9 +140,9 @@ struct S2Cfg {
   }
   static_assert(TAPS % TPS == 0, "taps per step must divide the taps");
   static_assert(B_DMA_F4 % 64 == 0 && B_PER >= 1, "whole 1-KiB LDS-DMA instructions; a wave issues B_PER of them or none");
-  static_assert(TERMS == 3 || TERMS == 2 || TERMS == 1 || TERMS == 0,
-                "3 = fp16 hi/lo split (fp32 accuracy), 2 = fp16 hi*hi + both cross terms in one block-scaled fp8 MFMA, 1 = plain fp16 operands, 0 = fp32 operands (exact fp32 MFMA)");
-  static_assert(TERMS == 1 || B_DMA_F4 % NTHR == 0, "split mode: every wave owns the same number of distinct 1-KiB pieces");
+  static_assert(TERMS == 4 || TERMS == 3 || TERMS == 2 || TERMS == 1 || TERMS == 0,
+                "3 = fp16 hi/lo split (fp32 accuracy), 2 = fp16 hi*hi + both cross terms in one block-scaled fp8 MFMA, 1 = plain fp16 operands, 4 = plain bf16 operands, 0 = fp32 operands (exact fp32 MFMA)");
+  static_assert(ONE || B_DMA_F4 % NTHR == 0, "split mode: every wave owns the same number of distinct 1-KiB pieces");
   static_assert(TH * TW * TN == BM && TPI % OCT == 0 && TPI >= OCT, "tile / loader mapping");
   static_assert(R >= 2, "ring needs >= 2 slots");
 };
@@ -155,6 +158,7 @@ __device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
 union F4H8b {
   float4 f4;
   f16x8 h8;
+  bf16x8 b8;
 };
 
 template <int N>
@@ -400,6 +404,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         }
         areg[j][0] = f32x4{hi.f4.x, hi.f4.y, hi.f4.z, hi.f4.w};
         areg[j][1] = f32x4{__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]), __builtin_bit_cast(float, q[2]), __builtin_bit_cast(float, q[3])};
+      } else if constexpr (TERMS == 4) {
+        F4H8b hi;  // bf16 operands (round to nearest even: v_cvt_pk_bf16_f32); no range clamp needed, bf16 has fp32's exponent
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hi.b8[k] = (__bf16)(ok ? v[k] : 0.f);
+        areg[j][0] = f32x4{hi.f4.x, hi.f4.y, hi.f4.z, hi.f4.w};
       } else {
         F4H8b hi, lo;
 #pragma unroll
@@ -673,7 +682,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
               for (int c = 0; c < NT; ++c) {
                 if constexpr (t == 0) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
                 if constexpr (t == 1) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bl[c].h8, acc[i][c], 0, 0, 0);
-                if constexpr (t == 2) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+                if constexpr (t == 2 && TERMS != 4) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].h8, bh[c].h8, acc[i][c], 0, 0, 0);
+                if constexpr (t == 2 && TERMS == 4) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b8, bh[c].b8, acc[i][c], 0, 0, 0);
               }
             if constexpr (t == T0) {
               // memory-side instructions of this step go out here, a few at a time, behind MFMAs that keep the pipe busy
@@ -1385,6 +1395,10 @@ int launch_conv_split2(const ConvArgs& a, hipStream_t s) {
   if (a.terms == 1) {  // plain fp16 operands, one MFMA per product (DRM_PREC_F16)
     if (a.taps == 9) return dispatch_s2_tile<9, 1>(a, s);
     return dispatch_s2_tile<1, 1>(a, s);
+  }
+  if (a.terms == 4) {  // plain bf16 operands, one MFMA per product (DRM_PREC_BF16)
+    if (a.taps == 9) return dispatch_s2_tile<9, 4>(a, s);
+    return dispatch_s2_tile<1, 4>(a, s);
   }
   if (a.terms == 2) {  // fp16 hi*hi + block-scaled fp8 cross terms (DRM_PREC_F16MX): the GroupNorm-fed 3x3 convs only
     DRM_REQUIRE(a.taps == 9 && a.gn_scale && !a.in_inv && a.w_img_stride_f4 == 0, "f16mx: 3x3 convs on a GroupNorm-ed input only");

@@ -138,9 +138,9 @@ struct Ctx {
   int N;
   int precision = PREC_FP32;
   bool dry() const { return ar->dry; }
-  bool split() const { return precision == PREC_F16X3 || precision == PREC_F16 || precision == PREC_F16MX; }
+  bool split() const { return precision == PREC_F16X3 || precision == PREC_F16 || precision == PREC_F16MX || precision == PREC_BF16; }
   // ConvArgs::terms of the pipeline kernel (PREC_F16MX: 3, and 2 on its mx_site launches)
-  int terms() const { return precision == PREC_F16 ? 1 : (precision == PREC_FP32 ? 0 : 3); }
+  int terms() const { return precision == PREC_F16 ? 1 : (precision == PREC_BF16 ? 4 : (precision == PREC_FP32 ? 0 : 3)); }
   bool mx() const { return precision == PREC_F16MX; }
 };
 Act new_act(Ctx& c, int C, int H, int W);

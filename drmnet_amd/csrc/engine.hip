@@ -256,7 +256,7 @@ int UNet::load(const float* const* ptrs, int count, hipStream_t s, int set) {
       DRM_HIP_CHECK(hipMemcpyAsync(wbuf + p.dst, ptrs[i], p.count * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else if (precision != PREC_FP32 && p.cinp % 32 == 0) {  // both fp16 modes use the pre-split, pre-scaled image
       DRM_TRY(launch_pack_conv_weight_split(ptrs[i], wbuf + p.dst, wbuf + p.scale_dst, reinterpret_cast<unsigned*>(wbuf + scratch_off), p.cout,
-                                            p.cin, p.taps, p.coutp, p.cinp, s, precision == PREC_F16MX && p.mx_site));
+                                            p.cin, p.taps, p.coutp, p.cinp, s, precision == PREC_F16MX && p.mx_site, precision == PREC_BF16));
     } else {
       DRM_TRY(launch_pack_conv_weight(ptrs[i], wbuf + p.dst, p.cout, p.cin, p.taps, p.coutp, p.cinp, s));
     }

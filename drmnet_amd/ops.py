@@ -14,8 +14,8 @@ from . import _lib
 
 def set_precision(precision: str) -> None:
     """Arithmetic of the drm_op_* entry points: "fp32" (default), "f16x3" (split fp16, fp32-accurate), "f16mx" (f16x3 with the res blocks'
-    3x3 convs on fp16 hi*hi + a block-scaled fp8 MFMA for the cross terms, ~7e-6 per block) or "f16" (reduced precision)."""
-    modes = {"fp32": 0, "f16x3": 1, "f16": 2, "f16mx": 3}
+    3x3 convs on fp16 hi*hi + a block-scaled fp8 MFMA for the cross terms, ~7e-6 per block), "f16" or "bf16" (reduced precision)."""
+    modes = {"fp32": 0, "f16x3": 1, "f16": 2, "f16mx": 3, "bf16": 4}
     if precision not in modes:
         raise ValueError(f"precision must be one of {list(modes)}")
     _lib.check(_lib.lib().drm_set_op_precision(modes[precision]))

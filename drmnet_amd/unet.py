@@ -137,7 +137,7 @@ class _HipUNetBase(nn.Module):
             pass
 
     # ------------------------------------------------------------------ arithmetic mode
-    PRECISIONS = {"fp32": 0, "f16x3": 1, "f16": 2, "f16mx": 3}
+    PRECISIONS = {"fp32": 0, "f16x3": 1, "f16": 2, "f16mx": 3, "bf16": 4}
 
     def set_precision(self, precision: str) -> "._HipUNetBase":
         """"fp32": exact fp32 products on v_mfma_f32_32x32x2_f32 (default).
@@ -145,7 +145,8 @@ class _HipUNetBase(nn.Module):
         16/3 x the fp32 matrix rate).
         "f16mx": f16x3 with the GroupNorm-fed 3x3 convs on fp16 hi*hi + one block-scaled fp8 MFMA for both cross terms (2/3 of the matrix-pipe
         cycles; 2.4e-5 .. 4e-5 rel-L2 per network against the reference: inside the 1e-4 contract, tests/test_gpu_f16mx.py).
-        "f16": REDUCED precision (fp16 operands, ~1e-3).  Weights are re-packed on the next forward."""
+        "f16" / "bf16": REDUCED precision (fp16 / bf16 operands, ~1e-3 / ~1e-2; bf16 is BASELINE configs[2] as written).  Weights are
+        re-packed on the next forward."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {list(self.PRECISIONS)}")
         _lib.check(_lib.lib().drm_unet_set_precision(self._h, self.PRECISIONS[precision]))

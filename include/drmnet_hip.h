@@ -93,6 +93,11 @@ int drm_unet_use_set(drm_unet* net, int set);
  *       |gamma| + |beta| (<= 7 |gamma| + |beta| here), so |gamma| would have to exceed ~500 before a value gets there; such an input comes out
  *       finite and saturated, not wrapped or NaN.  Networks with GroupNorm gains of that size belong in F16X3. */
 #define DRM_PREC_F16MX 3
+/*   4 = DRM_PREC_BF16 : REDUCED PRECISION, BASELINE configs[2] as written ("DDIM 50-step, batch 256, bf16").  Operands rounded to bf16 (8
+ *       significant bits, fp32's exponent range: no range guard needed), one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation, on the
+ *       same kernels as DRM_PREC_F16 -- same speed, three mantissa bits fewer (~1e-2 rel-L2 per network against ~1e-3).  Outside the 1e-4
+ *       contract; tests hold it to 3e-2. */
+#define DRM_PREC_BF16 4
 int drm_unet_set_precision(drm_unet* net, int precision);
 int drm_set_op_precision(int precision);
 

@@ -12,7 +12,7 @@ from oracle import unet as ou
 from test_gpu_ops import attn_manifest, block_inputs
 
 pytestmark = pytest.mark.gpu
-TOL = {"fp32": 2e-5, "f16x3": 2e-5, "f16mx": 2e-5, "f16": 5e-3}
+TOL = {"fp32": 2e-5, "f16x3": 2e-5, "f16mx": 2e-5, "f16": 5e-3, "bf16": 3e-2}
 
 
 @pytest.fixture(scope="module")
@@ -29,7 +29,7 @@ def run(P, x, precision, dev):
         ops.set_precision("fp32")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16mx", "f16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16mx", "f16", "bf16"])
 def test_attention_block_384_at_32x32_vs_reference_golden(dev, precision):
     gd = gold("attnblock_384_32x32")
     x, _ = block_inputs(384, 384, 32, 32, int(gd["n"]))
@@ -39,7 +39,7 @@ def test_attention_block_384_at_32x32_vs_reference_golden(dev, precision):
     assert err < TOL[precision]
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
 @pytest.mark.parametrize("n,h,w", [(3, 32, 64), (8, 32, 32), (5, 32, 32)])
 def test_attention_block_vs_oracle_metric_shape(dev, n, h, w, precision):
     """T = 2048 (the 3x128x256 metric shape's ds = 4 level) and T = 1024; N * T / 128 a multiple of 8 (XCD-grouped query tiles) and not"""
@@ -52,11 +52,11 @@ def test_attention_block_vs_oracle_metric_shape(dev, n, h, w, precision):
     e_all = rel_l2(out, ref)
     e_branch = rel_l2(out - x, ref - x.double())  # the residual x is added exactly: the attention branch itself
     print(f"attention 384 @{h}x{w} N={n} ({precision}): {e_all:.2e}, branch {e_branch:.2e}")
-    assert torch.isfinite(out).all() and e_all < TOL[precision] and e_branch < (1e-4 if precision != "f16" else 2e-2)
+    assert torch.isfinite(out).all() and e_all < TOL[precision] and e_branch < {"f16x3": 1e-4, "f16": 2e-2, "bf16": 1e-1}[precision]
     # a row of the batch == that image alone (per-image factors, no cross-image state)
     one = run(P, x[1:2].contiguous(), precision, dev)
     # (f16: the qkv conv in front runs another tile family at N = 1 -- its sums land on the other side of an fp16 rounding boundary for a few operands)
-    assert rel_l2(one[0], out[1]) < (1e-6 if precision != "f16" else 1e-4)
+    assert rel_l2(one[0], out[1]) < {"f16x3": 1e-6, "f16": 1e-4, "bf16": 1e-3}[precision]
 
 
 @pytest.mark.parametrize("vscale,qscale", [(3e4, 1.0), (1e-3, 30.0), (30.0, 1.0 / 30.0)])

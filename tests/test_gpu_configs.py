@@ -30,7 +30,8 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("B,precision", [(32, "f16x3"), (32, "f16mx"), (32, "f16"), (128, "f16mx"), (256, "f16x3"), (256, "f16mx"), (256, "f16")])
+@pytest.mark.parametrize("B,precision", [(32, "f16x3"), (32, "f16mx"), (32, "f16"), (32, "bf16"), (128, "f16mx"), (256, "f16x3"), (256, "f16mx"), (256, "f16"),
+                                         (256, "bf16")])  # (256, "bf16") is BASELINE configs[2]'s shard as written
 def test_obsnet_metric_shape_batches(dev, B, precision):
     gd = gold("full_obsnet_128x256")
     m = build(ou.OBSNET_CFG, "unet", int(gd["seed"]), dev).set_precision(precision)
