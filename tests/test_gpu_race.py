@@ -1,0 +1,20 @@
+"""The repetition screen of the hot kernels (tools/race_screen.py) inside the GPU suite (not a one-off artifact): every case runs several
+times on the same inputs and run k must equal run 0 up to the fp64 statistics atomics (2e-6 on an fp32 output) -- a torn tile, a stale LDS-DMA read, a
+lost split-K slab or an early read of the attention kernel's ring shows up as an O(1) difference on some repetition.  The quick set covers each
+mechanism once per arithmetic mode (wide persistent tiles, split-K with the fused finish, the small-map reduction, ragged tiles, the single-kernel
+attention with and without XCD grouping, attention on the conv pipeline); `python tools/race_screen.py 25` runs the full set."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_repetitions_are_identical_up_to_the_statistics_atomics():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no fallback)"
+    import race_screen
+
+    assert race_screen.run_screen(6, cases=race_screen.QUICK, verbose=True) == 0
