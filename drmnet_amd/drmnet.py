@@ -198,7 +198,8 @@ class DRMNet(nn.Module):
 
     def set_precision(self, precision: str) -> "DRMNet":
         """Conv arithmetic of both networks: "fp32" (exact fp32 MFMA), "f16x3" (split fp16, fp32-accurate, ~2.5x faster), "f16mx" (f16x3 with
-        fp8 cross terms on the 3x3 convs: ~3e-5 per network, ~3x faster) or "f16" (reduced precision)."""
+        fp8 cross terms on the 3x3 convs: ~3e-5 per network, ~3x faster), "auto" (f16mx per network only where a probe forward on the loaded
+        weights agrees with f16x3 to 5e-5, else f16x3: unet.set_precision_auto), "f16" / "bf16" (reduced precision)."""
         self.illnet_model.diffusion_model.set_precision(precision)
         self.refnet_model.diffusion_model.set_precision(precision)
         return self

@@ -147,12 +147,80 @@ class _HipUNetBase(nn.Module):
         cycles; 2.4e-5 .. 4e-5 rel-L2 per network against the reference: inside the 1e-4 contract, tests/test_gpu_f16mx.py).
         "f16" / "bf16": REDUCED precision (fp16 / bf16 operands, ~1e-3 / ~1e-2; bf16 is BASELINE configs[2] as written).  Weights are
         re-packed on the next forward."""
+        if precision == "auto":
+            return self.set_precision_auto()
         if precision not in self.PRECISIONS:
-            raise ValueError(f"precision must be one of {list(self.PRECISIONS)}")
+            raise ValueError(f"precision must be one of {list(self.PRECISIONS) + ['auto']}")
+        self.__dict__["_auto"] = None
+        return self._set_mode(precision)
+
+    def _set_mode(self, precision: str) -> "._HipUNetBase":
         _lib.check(_lib.lib().drm_unet_set_precision(self._h, self.PRECISIONS[precision]))
         self.precision = precision
         self._set_sig = {"live": None, "ema": None}
         return self
+
+    # "auto": f16mx only where it demonstrably holds.  f16mx carries about twenty times the rounding noise of exact fp32 (its cross terms keep four
+    # significant bits); on the shipped architectures with O(1) GroupNorm gains that is 2e-5 .. 4e-5 per network, but a network that amplifies rounding
+    # noise -- GroupNorm gains x 10 take RefNet from 3e-6 to 9e-4 (tests/test_gpu_round4.py) -- leaves the 1e-4 contract in f16mx while f16x3 stays at
+    # 1e-5.  So the choice is MEASURED on the weights actually loaded: one seeded probe forward in f16x3 and one in f16mx; f16mx is kept only if the
+    # two agree to `tolerance` (default 5e-5, half the contract), otherwise the network runs in f16x3.  Re-measured whenever the weights change.
+    AUTO_TOLERANCE = 5e-5
+
+    def set_precision_auto(self, tolerance: Optional[float] = None, probe_hw: Tuple[int, int] = (64, 64)) -> "._HipUNetBase":
+        self.__dict__["_auto"] = {"tolerance": float(self.AUTO_TOLERANCE if tolerance is None else tolerance), "probe_hw": tuple(probe_hw), "sig": None,
+                                  "report": None, "busy": False}
+        if self.precision not in ("f16x3", "f16mx"):
+            self._set_mode("f16x3")  # (until the first forward has weights on a GPU to measure with)
+        return self
+
+    @property
+    def auto_report(self) -> Optional[dict]:
+        """{"chosen", "rel_l2_f16mx_vs_f16x3", "tolerance", "probe"} of the last calibration, or None (not in auto mode / not yet measured)"""
+        a = self.__dict__.get("_auto")
+        return None if a is None else a["report"]
+
+    def calibrate_precision(self) -> Optional[dict]:
+        """Runs the auto-mode measurement now (weights must be on a GPU) and returns its report; None outside auto mode."""
+        self._auto_resolve()
+        return self.auto_report
+
+    @torch.no_grad()
+    def _auto_resolve(self) -> None:
+        a = self.__dict__.get("_auto")
+        if a is None or a["busy"]:
+            return
+        ps = self.param_tensors() if self._active_set == "live" else self._ema_source
+        if not ps or not ps[0].is_cuda:
+            return
+        sig = tuple((p.data_ptr(), p._version) for p in ps)
+        if sig == a["sig"]:
+            return
+        a["busy"] = True
+        try:
+            from . import synth
+
+            dev = ps[0].device
+            h, w = a["probe_hw"]
+            gen = torch.Generator().manual_seed(20261003)
+            ref = synth.synth_refmaps(1, h, w, 4321)
+            if self.in_channels == 6:  # [noised refmap | conditioning refmap], what all three shipped networks see
+                x = torch.cat([ref + 0.025 * torch.randn(ref.shape, generator=gen), ref], 1).contiguous().to(dev)
+            else:
+                x = torch.randn((1, self.in_channels, h, w), generator=gen).to(dev)
+            t_emb = torch.randn((1, self.model_channels), generator=gen).to(dev) if self._kind == 0 else None
+            ts = None if self._kind == 0 else torch.tensor([7], dtype=torch.int64, device=dev)
+            outs = {}
+            for mode in ("f16x3", "f16mx"):
+                self._set_mode(mode)
+                outs[mode] = self._run(x, None, t_emb, ts).double()
+            err = float((outs["f16mx"] - outs["f16x3"]).norm() / outs["f16x3"].norm().clamp_min(1e-300))
+            chosen = "f16mx" if err <= a["tolerance"] and bool(torch.isfinite(outs["f16mx"]).all()) else "f16x3"
+            self._set_mode(chosen)
+            a["sig"] = sig
+            a["report"] = {"chosen": chosen, "rel_l2_f16mx_vs_f16x3": err, "tolerance": a["tolerance"], "probe": f"1x{self.in_channels}x{h}x{w} seeded refmap-like input"}
+        finally:
+            a["busy"] = False
 
     # ------------------------------------------------------------------ weights
     def param_tensors(self) -> List[torch.Tensor]:
@@ -186,6 +254,7 @@ class _HipUNetBase(nn.Module):
     def sync_weights(self, force: bool = False) -> None:
         """Makes the engine's active weight image current: (re)packs it when its source tensors changed (load_state_dict,
         .to(device), an optimizer step, a new EMA shadow) and selects it."""
+        self._auto_resolve()
         which = self._active_set
         ps = self.param_tensors() if which == "live" else self._ema_source
         sig = (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)

@@ -124,7 +124,11 @@ def test_stress_weights_vs_reference(dev, name, cfg, kind, gain, precision):
         if gain == 3:
             assert e32 < (NET_TOL[precision] if precision != "f16mx" else CONTRACT)
         else:
-            assert e64 < max(10 * r64, CONTRACT if precision == "f16mx" else 2e-5)  # (noise-level comparison: exact fp32 lands at 2.4 x r64 on IllNet, 5.8 x on ObsNet 64x64)
+            # (noise-level comparison: exact fp32 lands at 2.4 x r64 on IllNet, 5.8 x on ObsNet 64x64.  f16mx carries ~20 x the rounding noise of
+            # exact fp32 -- four-bit cross terms -- and these networks amplify it like any other: 9e-4 on RefNet 2x32x64 where fp32 sits at 4e-5.  It is
+            # NOT expected to hold the contract under such gains; what is asserted is that it stays a noise effect (no range / saturation failure), and
+            # test_auto_precision_measures_the_loaded_weights below asserts that the default "auto" mode sends such weights to f16x3)
+            assert e64 < (max(100 * r64, CONTRACT) if precision == "f16mx" else max(10 * r64, 2e-5))
     del m
     torch.cuda.empty_cache()
 
@@ -220,3 +224,32 @@ def test_resize_vs_reference(dev):
         ops.resize(hdr.cpu(), (16, 16))
     with pytest.raises(RuntimeError):  # beyond the kernel's tap budget: an argument error, not a silent truncation
         ops.resize(torch.ones((1, 1, 16, 4096), device=dev), (16, 16), "bicubic")
+
+
+# --------------------------------------------------------------------------------------------- "auto": f16mx only where it measurably holds
+
+
+@pytest.mark.parametrize("rule,expect", [("normal", "f16mx"), ("stress:10", "f16x3")])
+def test_auto_precision_measures_the_loaded_weights(dev, rule, expect):
+    """set_precision("auto") (bench.py's default): one seeded probe forward in f16x3 and one in f16mx on the weights actually loaded; f16mx is kept
+    only if the two agree to 5e-5.  The synthetic weights of the benches and fixtures pass (RefNet ~3e-6); the same network with GroupNorm gains x 10
+    amplifies rounding noise forty-fold (f16mx 9e-4 against the reference, f16x3 1e-5) and must be sent to f16x3; new weights are re-measured."""
+    from drmnet_amd.unet import EncoderUNetModel
+
+    g = gold("stress10_refnet")
+    m = EncoderUNetModel(**ou.REFNET_CFG)
+    synth.load_synth(m, int(g["seed"]), rule=rule)
+    m = m.to(dev).set_precision("auto")
+    assert m.auto_report is None  # nothing measured before the first forward
+    xc, _ = full_inputs(2, 32, 64)
+    out = m(xc.to(dev), torch.from_numpy(g["t"])[:2].to(dev))
+    rep = m.auto_report
+    print(f"auto precision on RefNet with {rule} weights: {rep}")
+    assert rep["chosen"] == expect == m.precision and (rep["rel_l2_f16mx_vs_f16x3"] <= rep["tolerance"]) == (expect == "f16mx")
+    if rule != "normal":
+        e = rel_l2(out.cpu(), g["out64_2x32x64"])
+        assert e < 1e-4  # (in f16x3 the stressed network is back inside the contract: 1.4e-5)
+        synth.load_synth(m, synth.SEED_REFNET)  # other weights -> measured again on the next forward
+        m(xc.to(dev), torch.from_numpy(g["t"])[:2].to(dev))
+        assert m.auto_report["chosen"] == "f16mx" == m.precision
+    assert m.set_precision("f16x3").auto_report is None  # an explicit mode leaves auto
