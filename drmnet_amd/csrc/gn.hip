@@ -130,10 +130,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restr
       guard_shift[(size_t)n * C + c] = 0.f;
     }
   }
-  if (t < 32) {
+  {
+    // group sums in a fixed order, eight lanes per group (the 32 groups x 8 = the block): lane j of a group takes its channels j, j + 8, ... and the
+    // eight partial sums meet in three shuffle steps -- the serial form (one thread per group, up to 48 dependent fp64 loads) made this 5-6 us
+    // launch the most frequent kernel of a batch-1 step (111 per step)
+    const int g = t >> 3, j = t & 7;
     double m = 0.0, q = 0.0;
-    for (int k = 0; k < cpg; ++k) {
-      const int c = t * cpg + k;
+    for (int k = j; k < cpg; k += 8) {
+      const int c = g * cpg + k;
       if (c < C0) {
         const double2 v = mom0[(size_t)n * C0 + c];
         m += v.x * inv0;
@@ -144,12 +148,19 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restr
         q += v.y * inv1;
       }
     }
-    m /= cpg;
-    q /= cpg;
-    double var = q - m * m;
-    if (var < 0.0) var = 0.0;
-    g_mean[t] = (float)m;
-    g_rstd[t] = (float)(1.0 / sqrt(var + 1e-5));
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      m += __shfl_xor(m, o);
+      q += __shfl_xor(q, o);
+    }
+    if (j == 0) {
+      m /= cpg;
+      q /= cpg;
+      double var = q - m * m;
+      if (var < 0.0) var = 0.0;
+      g_mean[g] = (float)m;
+      g_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+    }
   }
   __syncthreads();
   for (int c = t; c < C; c += 256) {
