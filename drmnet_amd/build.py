@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libdrmnet_hip.so")
 SOURCES = ["conv.hip", "conv_split.hip", "conv_split2.hip", "gn.hip", "attn.hip", "attn_flash.hip", "misc.hip", "refmap.hip", "transform.hip", "engine.hip", "samplers.hip", "abi.hip", "profiler.hip"]
-HEADERS = ["common.h", "engine.h", "samplers.h", "profiler.h", os.path.join("..", "..", "include", "drmnet_hip.h")]
+HEADERS = ["common.h", "gn_fold.h", "engine.h", "samplers.h", "profiler.h", os.path.join("..", "..", "include", "drmnet_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
 

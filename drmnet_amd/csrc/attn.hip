@@ -225,6 +225,81 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
   }
 }
 
+// S = alpha q k^T of the short-sequence levels (T <= 256: the 16x16, 8x8 and 4x4 maps), latency form.  The 64x64-tile kernel above is a chain
+// of (load -> split -> LDS -> barrier -> MFMA -> barrier) rounds: 22 - 26 us per launch at any batch size, K = C = 384 ... 768 deep on ONE
+// workgroup per image at T = 64.  Here a workgroup owns a 32x32 score tile and its four waves split K: a lane loads the eight consecutive
+// channels of "its" q row and k row per 16-wide step straight into registers (the operand layout of v_mfma_f32_32x32x16: lane (r, h) holds
+// k = 8h .. 8h + 7 of row r), QK_UNR steps of loads in flight at a time, no LDS and no barrier in the loop; the four partial tiles meet in LDS
+// and are added in wave order (deterministic).  Same arithmetic as bgemm64s_kernel<true, TERMS> (fp16 hi / lo split of both operands), which it
+// replaces for S (deepening that kernel's K chunk to 128 per barrier pair was measured first: 23 -> 22 us, the rounds are not what it waits for).
+constexpr int QK_UNR = 4;
+template <int TERMS>
+__global__ __launch_bounds__(256) void qk_small_kernel(const float* __restrict__ Q, const float* __restrict__ Kp, float* __restrict__ S, int T, int C,
+                                                       int ld, long long sQ, long long sS, float alpha) {
+  __shared__ float part[4][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  Q += (size_t)blockIdx.z * sQ;
+  Kp += (size_t)blockIdx.z * sQ;
+  S += (size_t)blockIdx.z * sS;
+  const bool qin = m0 + r < T, kin = n0 + r < T;
+  const int steps = C / 16, per = (steps + 3) / 4;  // a contiguous K range per wave: consecutive steps share cache lines
+  const int s0 = wave * per, s1 = min(steps, s0 + per);
+  const float4* qp = reinterpret_cast<const float4*>(Q + (size_t)min(m0 + r, T - 1) * ld + 8 * h);
+  const float4* kp = reinterpret_cast<const float4*>(Kp + (size_t)min(n0 + r, T - 1) * ld + 8 * h);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int sb = s0; sb < s1; sb += QK_UNR) {
+    float4 qa[QK_UNR][2], ka[QK_UNR][2];
+#pragma unroll
+    for (int u = 0; u < QK_UNR; ++u) {
+      const int st = min(sb + u, s1 - 1);  // (a step past the range re-reads the last one and is not accumulated)
+      qa[u][0] = qp[4 * st]; qa[u][1] = qp[4 * st + 1];
+      ka[u][0] = kp[4 * st]; ka[u][1] = kp[4 * st + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < QK_UNR; ++u) {
+      if (sb + u < s1) {
+        float qv[8] = {qa[u][0].x, qa[u][0].y, qa[u][0].z, qa[u][0].w, qa[u][1].x, qa[u][1].y, qa[u][1].z, qa[u][1].w};
+        float kv[8] = {ka[u][0].x, ka[u][0].y, ka[u][0].z, ka[u][0].w, ka[u][1].x, ka[u][1].y, ka[u][1].z, ka[u][1].w};
+        if (!qin) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) qv[j] = 0.f;
+        }
+        if (!kin) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) kv[j] = 0.f;
+        }
+        AF4H8 ah, al, bh, bl;
+        if (TERMS == 4) {
+          round8_bf16(qv, 1.0f, ah.f4, al.f4);
+          round8_bf16(kv, 1.0f, bh.f4, bl.f4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.b8, bh.b8, acc, 0, 0, 0);
+        } else {
+          split8(qv, 1.0f, ah.f4, al.f4);
+          split8(kv, 1.0f, bh.f4, bl.f4);
+          if (TERMS == 3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h8, bh.h8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bl.h8, acc, 0, 0, 0);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bh.h8, acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[wave][((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[e];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j, row = idx >> 5, col = idx & 31;
+    const float v = ((part[0][row * 33 + col] + part[1][row * 33 + col]) + part[2][row * 33 + col]) + part[3][row * 33 + col];
+    if (m0 + row < T && n0 + col < T) S[(size_t)(m0 + row) * T + n0 + col] = alpha * v;
+  }
+}
+
 // in-place softmax over the last axis; one wave per row
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, long long rows, int T) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -513,19 +588,22 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
   const int tb = (T + 63) / 64;
   prof_tag(N, T, 1, C, C);
   ProfScope ps(PROF_ATTN, 4.0 * N * (double)T * T * C, 4.0 * N * ((double)T * 4 * C + 4.0 * T * T), s);
-  split = split && (C % 32 == 0) && (T % 32 == 0);
-  const int NB = attention_group(N, T);
+  // S = q k^T needs whole 32-chunks of C only (rows beyond T are masked); P v needs them of T: the 4x4 level (T = 16) of a 128x128 input keeps
+  // the exact-fp32 form for P v and takes the split form for S like every other level
+  const bool split_qk = split && (C % 32 == 0);
+  split = split_qk && (T % 32 == 0);
+  const int NB = attention_group(N, T), t32 = (T + 31) / 32;
   const long long sq = (long long)T * 3 * C;  // image stride of qkv
   for (int n0 = 0; n0 < N; n0 += NB) {
     const int nb = std::min(NB, N - n0);
     const float* qg = qkv + (size_t)n0 * sq;
     float* og = out + (size_t)n0 * T * C;
-    if (split && terms == 4)
-      hipLaunchKernelGGL((bgemm64s_kernel<true, 4>), dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha, 1.0f);
-    else if (split && terms == 1)
-      hipLaunchKernelGGL((bgemm64s_kernel<true, 1>), dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha, 1.0f);
-    else if (split)
-      hipLaunchKernelGGL((bgemm64s_kernel<true, 3>), dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha, 1.0f);
+    if (split_qk && terms == 4)
+      hipLaunchKernelGGL(qk_small_kernel<4>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha);
+    else if (split_qk && terms == 1)
+      hipLaunchKernelGGL(qk_small_kernel<1>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha);
+    else if (split_qk)
+      hipLaunchKernelGGL(qk_small_kernel<3>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha);
     else
       hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha);
     DRM_HIP_CHECK(hipGetLastError());

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include "gn_fold.h"
 
 namespace drm {
 
@@ -94,6 +95,7 @@ struct ConvArgs {
   const float* w_inv_img = nullptr;    // ... and its own 2^-k weight factor [N] (replaces w_inv_scale)
   int prof_kind = -1;                  // launch-profiler family override (-1 = by tap count, PROF_KINDS = no scope of its own)
   const float* in_inv = nullptr;       // split-precision path: [N] per-image 2^-k undoing the input staging factor (launch_act_pow2_scale)
+  GnFold gnf;                          // sparse launches (engine.hip gn_params): gn_scale / gn_shift (and a guard table set) are finalised by this launch's own prologue
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 // index of the pixel-tile family {TH, TW} that wastes the fewest GEMM rows on an H x W map (ties: the first = larger tile)

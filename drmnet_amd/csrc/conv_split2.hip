@@ -197,6 +197,22 @@ __device__ __forceinline__ void gload16x2(f32x4& d0, f32x4& d1, const void* p) {
   asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(d0), "=&v"(d1) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void tie_regs(f32x4& x0, f32x4& x1) { asm volatile("" : "+v"(x0), "+v"(x1)::"memory"); }
+// Agent-scope accesses of the fused split-K hand-off (sc1: coherent across the 8 XCD-private L2s by themselves, the way relaxed agent-scope atomics
+// are -- LLVM AMDGPU memory model, gfx942 rows "load / store atomic monotonic agent").  The slabs move only through these, so the hand-off needs
+// ordering (s_waitcnt vmcnt(0) before the ticket) but no L2 write-back / invalidate.
+#ifndef DRM_SK_MODE
+#define DRM_SK_MODE 0
+#endif
+#if DRM_SK_MODE == 2
+#define DRM_SK_SC "sc0 sc1"
+#else
+#define DRM_SK_SC "sc1"
+#endif
+// (s_nop 1: a store of more than 8 bytes reads its data registers after issue -- the wait states the compiler inserts before it overwrites them
+//  are invisible to it inside asm; without them the next quad transpose corrupted the slab)
+__device__ __forceinline__ void gstore16_agent(void* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off " DRM_SK_SC "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void gload16_agent(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off " DRM_SK_SC : "=&v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void tie_reg(f32x4& x) { asm volatile("" : "+v"(x)::"memory"); }
 
 // 4 x 4 transpose across the four lanes of a quad: in, lane q holds x_k = M[q][k]; out, lane q holds x_k = M[k][q].
 // Two butterfly stages (lane bit 0 with register pairs (0,1), (2,3); lane bit 1 with pairs (0,2), (1,3)); each moves one register
@@ -280,6 +296,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   bool stamp_on = false;
   if (a.stamp_out && (int)blockIdx.x == (a.stamp_block & 0xFFFF))
     for (int k = tid; k < C::NW * 240; k += C::NTHR) stamp_lds[k] = 0;
+  stamp_on = a.stamp_out && (int)blockIdx.x == (a.stamp_block & 0xFFFF) && a.stamp_tile0 == 0;  // (first tile recorded: the prologue too)
+  S2_STAMP(60);  // kernel entry
 #endif
 
   const int Ctot = a.C0 + a.C1;
@@ -545,8 +563,37 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
       issue_G(gseq++, gi++, tp.wofs);
     }
   }
-  load_A(cur, 0);
+  S2_STAMP(61);  // first weight groups requested
+  if (a.gnf.mom0) {
+    // Sparse launches (batch-1 steps): the GroupNorm tables this launch stages through are finalised here, by every workgroup (identical values),
+    // instead of by a launch of their own -- 111 launches of ~5 us per batch-1 DRMNet step; the weight groups above are already in flight.
+    // The raw activation loads of the first chunk go out first (they do not depend on the tables).  Scratch: the activation tile, not yet
+    // written.  One image and room in the tile: the first chunk takes its (scale, shift) from an LDS copy of the tables -- no wait for the
+    // global tables to be written and read back; later chunks read the global tables.
+    float* scr = reinterpret_cast<float*>(As);
+    const bool tab_in_lds = a.N == 1 && (80 + 2 * Ctot) * (int)sizeof(float) <= C::A_F4 * 16;
+#pragma unroll
+    for (int p = 0; p < C::A_SLOTS; ++p) load_A_piece(cur, 0, p);
+    for (int n = 0; n < a.N; ++n) gn_finalize_image(a.gnf, n, tid, C::NTHR, scr, tab_in_lds ? scr + 80 : nullptr);
+    S2_STAMP(62);  // GroupNorm tables finalised
+    // (gn_finalize_image's barriers order LDS only: a wave's table stores are complete after ITS vmcnt(0) wait, everyone's after the barrier
+    //  that follows it -- before any lane reads a table entry another wave wrote)
+    wait_vmcnt<0>();
+    if (!tab_in_lds) {
+      gn_lds_barrier();
+      load_A_piece(cur, 0, C::A_SLOTS);
+    } else {  // (no table loads for this chunk: the wait below is vmcnt(0), not a counted one)
+      const float4* t4 = reinterpret_cast<const float4*>(scr + 80 + chunk0 * C::KC + 8 * l_o);
+      const float4 s0 = t4[0], s1 = t4[1], b0 = t4[Ctot / 4], b1 = t4[Ctot / 4 + 1];
+      sc[0] = f32x4{s0.x, s0.y, s0.z, s0.w}; sc[1] = f32x4{s1.x, s1.y, s1.z, s1.w};
+      sh[0] = f32x4{b0.x, b0.y, b0.z, b0.w}; sh[1] = f32x4{b1.x, b1.y, b1.z, b1.w};
+      gn_lds_barrier();  // every lane has its table entries before the tile is written over them
+    }
+  } else {
+    load_A(cur, 0);
+  }
   wait_vmcnt<0>();
+  S2_STAMP(63);  // first activation tile (and the first weight groups) landed
   store_A(As);
   if (TAPS == 1) {  // 1x1: the activations of step 1 are requested a full step ahead
     if (nchunks > 1) load_A(cur, 1);
@@ -554,6 +601,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  S2_STAMP(64);  // prologue done
 
   // Per step (group g of chunk c of the current tile; g is a compile-time constant):
   //   (1) issue the DMA of the group R-1 steps ahead into the slot consumed one step ago (it may belong to the NEXT tile),
@@ -987,6 +1035,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
               continue;
             }
 #endif
+            if constexpr (FUSE) {
+              if (fused) {  // the slab of a fused split-K launch: agent-scope stores (see gstore16_agent)
+                if (okg[g]) gstore16_agent(&out_s[(pixb[g] + (r & 3)) * a.Cout + cq], f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]});
+                continue;
+              }
+            }
             if (okg[g]) *reinterpret_cast<float4*>(&out_s[(pixb[g] + (r & 3)) * a.Cout + cq]) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
           }
         }
@@ -1009,30 +1063,35 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         S2_STAMP(23 + 4 * (i * NT + c));  // statistics atomics issued
       }
       if constexpr (FUSE) {
-        // Fused split-K finish: hand this split's slab over (every storing wave drains its stores, the workgroup meets, ONE lane releases at
-        // agent scope and draws the tile's ticket -- cdna_hip_programming.md Guideline 16); the workgroup that arrives LAST acquires, sums the
-        // ks slabs of its tile IN SLAB ORDER (its own included: the result does not depend on who was last) and runs the full epilogue --
-        // bias, emb, residual, output statistics -- into the real output.  No second launch, no per-block statistics table.
+        // Fused split-K finish: hand this split's slab over (every storing wave drains its agent-scope slab stores, the workgroup meets, ONE lane
+        // draws the tile's ticket with an agent-scope atomic); the workgroup that arrives LAST reads the ks slabs of its tile with agent-scope
+        // loads, sums them IN SLAB ORDER (its own included: the result does not depend on who was last) and runs the full epilogue -- bias, emb,
+        // residual, output statistics -- into the real output.  No second launch, no per-block statistics table.
+        // [r4] The slabs used to be ordinary stores / loads around an agent-scope release fence (buffer_wbl2: the XCD's whole L2 written back) and
+        // acquire fences (buffer_inv: its L2 invalidated, every wave): with 512 workgroups doing so at once the hand-off measured 40k cycles
+        // (19 us) of a 48 us batch-1 launch at the 64x64 level -- drain 7k, release + ticket 10k, acquire 12k.  Data that only ever moves through
+        // sc1 accesses needs no cache maintenance, only the ordering: stores complete (vmcnt(0)) -> barrier -> ticket -> barrier -> loads.
         if (fused) {
           __shared__ int s_last_tile;
+          S2_STAMP(70);  // slab stores issued
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          S2_STAMP(71);  // ... and complete at agent scope
           __builtin_amdgcn_s_barrier();
           if (tid == 0) {
+#if DRM_SK_MODE == 1 || DRM_SK_MODE == 3
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const bool last = __hip_atomic_fetch_add(a.tile_ticket + (x_start + k_tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ks - 1;
-            if (last) {
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            s_last_tile = last;
+#endif
+            s_last_tile = __hip_atomic_fetch_add(a.tile_ticket + (x_start + k_tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ks - 1;
           }
           __syncthreads();
+          S2_STAMP(72);  // ticket drawn
           if (s_last_tile) {
-            // every wave of the finishing workgroup acquires for itself (one buffer_inv each): the slab loads below no longer lean on lane 0's
-            // invalidate having cleared the CU-wide L1 for the other waves (inside the HIP memory model now)
+#if DRM_SK_MODE == 1 || DRM_SK_MODE == 4
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            S2_STAMP(73);
             const int col = wn * 32 + r, co = cur.co0 + col;
             const int cq = cur.co0 + wn * 32 + (r & ~3);
             float v[16];
@@ -1045,15 +1104,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             for (int e = 0; e < 16; ++e) rv[e] = a.res ? a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co] : 0.f;
 #pragma unroll
             for (int g2 = 0; g2 < 4; g2 += 2) {  // two row groups at a time: 2 x ks float4 loads in flight
-              float4 t[2][8];
+              f32x4 t[2][8];
 #pragma unroll
               for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                  if (k < ks) t[gg][k] = *reinterpret_cast<const float4*>(&a.split_ws[(size_t)k * a.split_stride + (pixb[g2 + gg] + (r & 3)) * a.Cout + cq]);
+                  // (always issued, on slab 0 beyond ks: an asm load under a branch leaves its destination to a phi copy that may run before it lands)
+                  gload16_agent(t[gg][k], &a.split_ws[(size_t)(k < ks ? k : 0) * a.split_stride + (pixb[g2 + gg] + (r & 3)) * a.Cout + cq]);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+              for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tie_reg(t[gg][k]);
 #pragma unroll
               for (int gg = 0; gg < 2; ++gg) {
-                float4 sacc = t[gg][0];
+                f32x4 sacc = t[gg][0];
 #pragma unroll
                 for (int k = 1; k < 8; ++k)
                   if (k < ks) { sacc.x += t[gg][k].x; sacc.y += t[gg][k].y; sacc.z += t[gg][k].z; sacc.w += t[gg][k].w; }
@@ -1062,6 +1127,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
                 quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], r);  // back to the accumulator layout: one channel, four pixels
               }
             }
+            S2_STAMP(74);  // slabs summed
             float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -1093,6 +1159,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
               }
             }
             fused_last = true;
+            S2_STAMP(75);  // finishing epilogue issued
           }
         }
       }
@@ -1183,7 +1250,7 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     // DRM_S2_STAMP_FILE=<path> [DRM_S2_STAMP_BLOCK=<workgroup>] [DRM_S2_STAMP_TILE0=<first recorded tile>]: appends one record
     // per 8-wave launch that has the 7.5 KiB of LDS to spare
     static const char* stamp_file = getenv("DRM_S2_STAMP_FILE");
-    if (stamp_file && C::NW == 8 && lds_bytes + 7680 <= di->lds_per_cu) {
+    if (stamp_file && lds_bytes + 7680 <= di->lds_per_cu) {
       static unsigned* dbuf = nullptr;
       if (!dbuf) DRM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 8192));
       DRM_HIP_CHECK(hipMemsetAsync(dbuf, 0, 8192, s));
@@ -1256,9 +1323,14 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
   }
-  if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
-  if (a.ksplit > 1 && a.split_ws) return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS, TERMS, false, true>(a, s);  // (conv_split_ksplit: only ever here)
-  return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RG, TPS, TERMS>(a, s);
+#ifdef DRM_S2_RG_SPARSE
+  constexpr int RS = (TAPS == 9) ? DRM_S2_RG_SPARSE : RG;
+#else
+  constexpr int RS = RG;
+#endif
+  if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RS, TPS, TERMS>(a, s);
+  if (a.ksplit > 1 && a.split_ws) return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RS, TPS, TERMS, false, true>(a, s);  // (conv_split_ksplit: only ever here)
+  return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RS, TPS, TERMS>(a, s);
 }
 
 // Maps that are not a whole number of tiles (any H, W the reference accepts other than the shipped sizes): 128-row tiles on 4 waves,

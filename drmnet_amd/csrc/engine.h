@@ -156,6 +156,7 @@ float* plan_splitk(Ctx& c, ConvArgs& a);  // sets a.ksplit / a.split_stride from
 int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, const unsigned* absmax_bits, int Ctab, int absmax_parts = 1);
 // ensure_moments on both sources + gn_finalize into (scale, shift)
 // guard_for (optional): a split conv reading (x0 | x1) un-normalised gets its range-guard tables from the same launch
-int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift, ConvArgs* guard_for = nullptr);
+int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift, ConvArgs* guard_for = nullptr,
+              ConvArgs* fold_into = nullptr);  // fold_into: the consumer conv finalises the tables itself on sparse launches (ConvArgs::gnf)
 
 }  // namespace drm

@@ -370,7 +370,11 @@ int raw_input_guard(Ctx& c, ConvArgs& a, Act* x0, int lo0, int hi0, Act* x1, con
   return DRM_OK;
 }
 
-int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift, ConvArgs* guard_for) {
+// fold_into: the split-pipeline conv that stages through (scale, shift) -- its shape fields already set.  On sparse launches (few images) that
+// launch finalises the tables in its own prologue (ConvArgs::gnf, gn_fold.h) and no gn_finalize launch is made: at batch 1 a ~5 us launch per
+// GroupNorm was 111 launches = a tenth of the DRMNet step.
+constexpr int GN_FOLD_MAX_N = 4;
+int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, float* scale, float* shift, ConvArgs* guard_for, ConvArgs* fold_into) {
   DRM_TRY(ensure_moments(c, x0));
   if (x1) DRM_TRY(ensure_moments(c, *x1));
   // the same launch can also produce the range-guard tables of a split conv that reads (x0 | x1) un-normalised (skip_connection)
@@ -387,6 +391,14 @@ int gn_params(Ctx& c, Act& x0, Act* x1, const float* gamma, const float* beta, f
   if (c.dry()) return DRM_OK;
   auto inv = [](const Act& a) { return a.mom_sums ? 1.0 / ((double)(a.H >> a.up) * (a.W >> a.up)) : 1.0; };
   auto cnt = [](const Act& t) { return t.mom_sums ? 0.0 : (double)(t.H >> t.up) * (t.W >> t.up); };
+  if (fold_into && c.N <= GN_FOLD_MAX_N && on_pipeline(c, *fold_into)) {
+    GnFold& f = fold_into->gnf;
+    f.mom0 = x0.mom; f.C0 = x0.C; f.inv0 = inv(x0); f.cnt0 = cnt(x0);
+    f.mom1 = x1 ? x1->mom : nullptr; f.C1 = x1 ? x1->C : 0; f.inv1 = x1 ? inv(*x1) : 1.0; f.cnt1 = x1 ? cnt(*x1) : 0.0;
+    f.gamma = gamma; f.beta = beta; f.scale = scale; f.shift = shift;
+    f.guard_scale = gs; f.guard_shift = gh; f.guard_inv = gi;
+    return DRM_OK;
+  }
   return launch_gn_finalize(x0.mom, x0.C, inv(x0), x1 ? x1->mom : nullptr, x1 ? x1->C : 0, x1 ? inv(*x1) : 1.0, gamma, beta, c.N, scale, shift, c.s,
                             cnt(x0), x1 ? cnt(*x1) : 0.0, gs, gh, gi);
 }
@@ -412,10 +424,10 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
   float* sc2 = c.ar->alloc<float>((size_t)c.N * r.cout);
   float* sh2 = c.ar->alloc<float>((size_t)c.N * r.cout);
   ConvArgs k;  // skip_connection: 1x1 conv on the raw (un-normalised) block input; its range-guard tables come out of the same launch
-  DRM_TRY(gn_params(c, x0, x1, Wb + r.n1_w, Wb + r.n1_b, sc1, sh1, r.has_skip ? &k : nullptr));
   ConvArgs a;  // in_layers conv: GroupNorm(x0 | x1) -> SiLU -> 3x3 + emb
   a.src0 = x0.p; a.src1 = x1 ? x1->p : nullptr; a.C0 = C0; a.C1 = C1; a.up0 = x0.up;
   a.N = c.N; a.H = H; a.W = W; a.taps = 9; a.Cout = r.cout; a.mx_site = 1;
+  DRM_TRY(gn_params(c, x0, x1, Wb + r.n1_w, Wb + r.n1_b, sc1, sh1, r.has_skip ? &k : nullptr, &a));
   float* ws1 = plan_splitk(c, a);
   if (!c.dry()) {
     a.gn_scale = sc1; a.gn_shift = sh1; a.silu = 1;
@@ -424,9 +436,9 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
     a.out = h1.p;
     DRM_TRY(run_conv(c, a, Wb, r.c1_s, &h1, ws1));
   }
-  DRM_TRY(gn_params(c, h1, nullptr, Wb + r.n2_w, Wb + r.n2_b, sc2, sh2));
   ConvArgs b;  // out_layers conv: GroupNorm(h1) -> SiLU -> 3x3 + residual
   b.src0 = h1.p; b.C0 = r.cout; b.N = c.N; b.H = H; b.W = W; b.taps = 9; b.Cout = r.cout; b.mx_site = 1;
+  DRM_TRY(gn_params(c, h1, nullptr, Wb + r.n2_w, Wb + r.n2_b, sc2, sh2, nullptr, &b));
   float* ws2 = plan_splitk(c, b);
   float* wsk = nullptr;
   if (r.has_skip) {
@@ -458,7 +470,9 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   const size_t mark = c.ar->mark();
   float* sc = c.ar->alloc<float>((size_t)c.N * C);
   float* sh = c.ar->alloc<float>((size_t)c.N * C);
-  DRM_TRY(gn_params(c, x, nullptr, Wb + l.n_w, Wb + l.n_b, sc, sh));
+  ConvArgs a;  // qkv: GroupNorm(x) -> 1x1
+  a.C0 = C; a.N = c.N; a.H = H; a.W = W; a.taps = 1; a.Cout = 3 * C;
+  DRM_TRY(gn_params(c, x, nullptr, Wb + l.n_w, Wb + l.n_b, sc, sh, nullptr, &a));
   Act qkv_act = new_act(c, 3 * C, H, W);  // its per-channel sums (fused into the qkv conv's epilogue) bound |v| >= |attention output|
   float* qkv = qkv_act.p;
   const bool flash = c.split() && attention_flash_applicable(T, C, c.terms());  // the long-sequence level: one kernel, no score matrix (attn_flash.hip)
@@ -467,8 +481,6 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   const bool on_conv = flash || (c.split() && attention_conv_applicable(T, C, H, W, c.terms()));  // the T >= 512 levels: both GEMMs on the conv pipeline
   float* aws = flash ? c.ar->alloc<float>(attention_flash_workspace_floats(c.N, T, C)) : on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C)) : nullptr;
   ConvArgs p;  // proj_out: 1x1 conv on the raw attention output, a convex combination of v rows: max |att| <= max |v|
-  ConvArgs a;  // qkv: GroupNorm(x) -> 1x1
-  a.C0 = C; a.N = c.N; a.H = H; a.W = W; a.taps = 1; a.Cout = 3 * C;
   float* wsq = plan_splitk(c, a);
   p.C0 = C; p.N = c.N; p.H = H; p.W = W; p.taps = 1; p.Cout = C;
   float* wsp = plan_splitk(c, p);
@@ -624,7 +636,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   float* sc = c.ar->alloc<float>((size_t)N * final_ch);
   float* sh = c.ar->alloc<float>((size_t)N * final_ch);
   DRM_TRY(arena_ok(c));
-  DRM_TRY(gn_params(c, *h, nullptr, Wb + on_w, Wb + on_b, sc, sh));
+  DRM_TRY(gn_params(c, *h, nullptr, Wb + on_w, Wb + on_b, sc, sh, nullptr, nullptr));
   if (!c.dry()) {
     if (desc.kind == 0) {
       ConvArgs a;

@@ -12,6 +12,7 @@
 // HBM-bound pass: reads the tensor once with 16-B/lane coalesced loads; wave/LDS tree reductions, partial
 // sums per slab, final accumulation in double.
 #include "common.h"
+#include "gn_fold.h"
 #include "profiler.h"
 
 namespace drm {
@@ -97,78 +98,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double2* __restr
                                                            float* __restrict__ scale, float* __restrict__ shift, double cnt0, double cnt1,
                                                            float* __restrict__ guard_scale, float* __restrict__ guard_shift,
                                                            float* __restrict__ guard_inv) {
-  __shared__ float g_mean[32], g_rstd[32];
-  const int n = blockIdx.x;
-  const int C = C0 + C1, cpg = C / 32;
-  const int t = threadIdx.x;
-  if (guard_scale) {
-    __shared__ double red[4];
-    __shared__ float s_scale;
-    double m = 0.0;
-    for (int c = t; c < C; c += 256)
-      m = fmax(m, c < C0 ? mom0[(size_t)n * C0 + c].y * (cnt0 > 0 ? cnt0 : 1.0) : mom1[(size_t)n * C1 + (c - C0)].y * (cnt1 > 0 ? cnt1 : 1.0));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-    if ((t & 63) == 0) red[t >> 6] = m;
-    __syncthreads();
-    if (t == 0) {
-      const double bound = sqrt(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
-      int k = 0;
-      if (bound > 0.0 && bound < INFINITY) {
-        int e;
-        frexp(bound, &e);
-        k = 15 - e;
-        k = k > 90 ? 90 : (k < -90 ? -90 : k);
-      }
-      s_scale = ldexpf(1.0f, k);
-      guard_inv[n] = ldexpf(1.0f, -k);
-    }
-    __syncthreads();
-    const float gs = s_scale;
-    for (int c = t; c < C; c += 256) {
-      guard_scale[(size_t)n * C + c] = gs;
-      guard_shift[(size_t)n * C + c] = 0.f;
-    }
-  }
-  {
-    // group sums in a fixed order, eight lanes per group (the 32 groups x 8 = the block): lane j of a group takes its channels j, j + 8, ... and the
-    // eight partial sums meet in three shuffle steps -- the serial form (one thread per group, up to 48 dependent fp64 loads) made this 5-6 us
-    // launch the most frequent kernel of a batch-1 step (111 per step)
-    const int g = t >> 3, j = t & 7;
-    double m = 0.0, q = 0.0;
-    for (int k = j; k < cpg; k += 8) {
-      const int c = g * cpg + k;
-      if (c < C0) {
-        const double2 v = mom0[(size_t)n * C0 + c];
-        m += v.x * inv0;
-        q += v.y * inv0;
-      } else {
-        const double2 v = mom1[(size_t)n * C1 + (c - C0)];
-        m += v.x * inv1;
-        q += v.y * inv1;
-      }
-    }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
-      m += __shfl_xor(m, o);
-      q += __shfl_xor(q, o);
-    }
-    if (j == 0) {
-      m /= cpg;
-      q /= cpg;
-      double var = q - m * m;
-      if (var < 0.0) var = 0.0;
-      g_mean[g] = (float)m;
-      g_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
-    }
-  }
-  __syncthreads();
-  for (int c = t; c < C; c += 256) {
-    const int g = c / cpg;
-    const float sc = g_rstd[g] * gamma[c];
-    scale[(size_t)n * C + c] = sc;
-    shift[(size_t)n * C + c] = beta[c] - g_mean[g] * sc;
-  }
+  __shared__ __attribute__((aligned(16))) float scratch[72];
+  GnFold f;
+  f.mom0 = mom0; f.mom1 = mom1; f.C0 = C0; f.C1 = C1; f.inv0 = inv0; f.inv1 = inv1; f.cnt0 = cnt0; f.cnt1 = cnt1;
+  f.gamma = gamma; f.beta = beta; f.scale = scale; f.shift = shift;
+  f.guard_scale = guard_scale; f.guard_shift = guard_shift; f.guard_inv = guard_inv;
+  gn_finalize_image(f, blockIdx.x, threadIdx.x, 256, scratch);  // (gn_fold.h: the same code runs in the prologue of sparse conv launches)
 }
 
 // Range guard of the split-precision path for UN-normalised conv inputs (ResBlock skip_connection, AttentionBlock proj_out, the

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float4* __restrict_
   const int ql = threadIdx.x % QL, pl = threadIdx.x / QL, PL = 256 / QL;
   const int HWo = Ho * Wo, W = Wo * 2;
   const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, HWo);
-  for (int q0 = 0; q0 < q4; q0 += QL) {  // (every thread runs every pass: the statistics fold has barriers)
+  // (every thread runs every pass: the statistics fold has barriers; blockIdx.z strides the channel passes when the launch is sparse)
+  for (int q0 = blockIdx.z * QL; q0 < q4; q0 += QL * gridDim.z) {
     const int q = q0 + ql;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
     for (int p = p0 + pl; p < p1 && q < q4; p += PL) {
@@ -145,9 +146,18 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float4* __restrict_
 
 int launch_avgpool2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s, double2* stat) {
   DRM_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "avgpool2 shape");
-  const int q4 = C / 4, QL = q4 >= 64 ? 64 : (q4 >= 32 ? 32 : (q4 >= 16 ? 16 : (q4 >= 8 ? 8 : 4)));
-  const int HWo = (H / 2) * (W / 2), ppb = 256;  // one fp64 atomic per (256-pixel block, channel, moment)
-  hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)((HWo + ppb - 1) / ppb), (unsigned)N), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+  const int q4 = C / 4, HWo = (H / 2) * (W / 2);
+  int QL = q4 >= 64 ? 64 : (q4 >= 32 ? 32 : (q4 >= 16 ? 16 : (q4 >= 8 ? 8 : 4)));
+  // One fp64 atomic per (pixel block, channel, moment), 256-pixel blocks on full launches.  A sparse launch (small batch / deep level: the
+  // batch-1 step ran its poolings on 1 - 16 workgroups, 18 - 56 us each) first narrows the channel lanes -- more channel passes, each its own
+  // workgroup (blockIdx.z), no extra atomics -- and then shortens the pixel blocks, up to 16 per image: the atomics of one (image, channel)
+  // serialise in L2 at ~0.18 us each (512 pixel blocks per image measured 91 us).
+  int ppb = 256;
+  auto blocks = [&]() { return (long long)N * ((HWo + ppb - 1) / ppb) * ((q4 + QL - 1) / QL); };
+  while (blocks() < 256 && QL > 8) QL >>= 1;
+  while (blocks() < 256 && (HWo + ppb - 1) / ppb < 16 && ppb > 256 / QL) ppb >>= 1;
+  const int passes = (q4 + QL - 1) / QL;
+  hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)((HWo + ppb - 1) / ppb), (unsigned)N, (unsigned)passes), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
                      reinterpret_cast<float4*>(out), stat, H / 2, W / 2, q4, QL, ppb);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
@@ -234,7 +244,58 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
   }
 }
 
+// Few batch rows (the batch-1 step of scripts/estimate.py): the matrix-core form above walks a weight row with ONE dependent load pair per 16
+// features (26 us for the 512 -> 11.7k emb_layers product at N = 1); here a wave owns one output feature, its 64 lanes read the weight row as
+// coalesced float4 and meet in a shuffle tree, so a launch has O waves in flight and streams the weights once.  LN_ROWS batch rows per pass.
+constexpr int LN_ROWS = 4;
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ out, int N, int I, int O, int silu_in, int silu_out) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= O) return;
+  const float4* wr = reinterpret_cast<const float4*>(w + (size_t)o * I);
+  for (int n0 = 0; n0 < N; n0 += LN_ROWS) {
+    float acc[LN_ROWS];
+#pragma unroll
+    for (int j = 0; j < LN_ROWS; ++j) acc[j] = 0.f;
+    for (int q = lane; q < I / 4; q += 64) {
+      const float4 wv = wr[q];
+#pragma unroll
+      for (int j = 0; j < LN_ROWS; ++j) {
+        if (n0 + j < N) {
+          float4 v = reinterpret_cast<const float4*>(in + (size_t)(n0 + j) * I)[q];
+          if (silu_in) {
+            v.x = silu_m(v.x); v.y = silu_m(v.y); v.z = silu_m(v.z); v.w = silu_m(v.w);
+          }
+          acc[j] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_ROWS; ++j) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off);
+    }
+    if (lane == 0) {
+      const float bias = b ? b[o] : 0.f;
+#pragma unroll
+      for (int j = 0; j < LN_ROWS; ++j) {
+        if (n0 + j < N) {
+          float v = acc[j] + bias;
+          if (silu_out) v = silu_m(v);
+          out[(size_t)(n0 + j) * O + o] = v;
+        }
+      }
+    }
+  }
+}
+
 int launch_linear(const float* in, const float* w, const float* b, float* out, int N, int I, int O, int silu_in, int silu_out, hipStream_t s) {
+  if (N <= LN_ROWS && I % 16 == 0) {  // (same 16-byte row alignment as the matrix-core form)
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((O + 3) / 4), dim3(256), 0, s, in, w, b, out, N, I, O, silu_in, silu_out);
+    DRM_HIP_CHECK(hipGetLastError());
+    return DRM_OK;
+  }
   if (I % 16 == 0 && I >= 16) {
     hipLaunchKernelGGL(linear_mfma_kernel, dim3((O + 127) / 128, (N + 31) / 32), dim3(256), 0, s, in, w, b, out, N, I, O, silu_in, silu_out);
     DRM_HIP_CHECK(hipGetLastError());
@@ -274,41 +335,46 @@ int launch_timestep_embedding(const int64_t* t, const float* tf, float* out, int
 __global__ __launch_bounds__(256) void encoder_head_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ w,
                                                            const float* __restrict__ b, float* __restrict__ out, int HW, int C, int O) {
-  extern __shared__ float pooled[];  // [C] + 4 reduction slots
-  float* red = pooled + C;
-  __shared__ float part[4][64];
+  extern __shared__ float pooled[];  // [C] pooled activations + [4][C] pixel-lane partial sums
+  float* part = pooled + C;
   const int n = blockIdx.x, tid = threadIdx.x;
   // 64 channel lanes x 4 pixel lanes: a thread walks every 4th pixel of its channel (one serial chain of HW dependent loads per
-  // thread made this kernel 80 us at HW = 512); the four partial sums of a channel are added in a fixed order
+  // thread made this kernel 80 us at HW = 512); the four partial sums of a channel are added in a fixed order.  One barrier for
+  // all channel passes and none in the projection (a wave per output feature): 25 -> 8 us in the batch-1 step.
   const int cl = tid & 63, pl = tid >> 6;
-  for (int c0 = 0; c0 < C; c0 += 64) {
-    const int c = c0 + cl;
-    float acc = 0.f;
-    if (c < C) {
-      const float sc = scale[(size_t)n * C + c], sh = shift[(size_t)n * C + c];
+  const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)n * HW * C);
+  const float4* sc4 = reinterpret_cast<const float4*>(scale + (size_t)n * C);
+  const float4* sh4 = reinterpret_cast<const float4*>(shift + (size_t)n * C);
+  const int q4 = C >> 2;
+  for (int q = cl; q < q4; q += 64) {  // a channel quad per lane: 16-byte loads, C / 256 rounds of load latency instead of C / 64
+    const float4 sc = sc4[q], sh = sh4[q];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-      for (int p = pl; p < HW; p += 4) acc += silu_m(x[((size_t)n * HW + p) * C + c] * sc + sh);
+    for (int p = pl; p < HW; p += 4) {
+      const float4 v = x4[(size_t)p * q4 + q];
+      acc.x += silu_m(v.x * sc.x + sh.x);
+      acc.y += silu_m(v.y * sc.y + sh.y);
+      acc.z += silu_m(v.z * sc.z + sh.z);
+      acc.w += silu_m(v.w * sc.w + sh.w);
     }
-    part[pl][cl] = acc;
-    __syncthreads();
-    if (pl == 0 && c < C) pooled[c] = (((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl]) / (float)HW;
-    __syncthreads();
+    *reinterpret_cast<float4*>(&part[pl * C + 4 * q]) = acc;
   }
-  for (int o = 0; o < O; ++o) {
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) pooled[c] = (((part[c] + part[C + c]) + part[2 * C + c]) + part[3 * C + c]) / (float)HW;
+  __syncthreads();
+  for (int o = pl; o < O; o += 4) {
     float acc = 0.f;
-    for (int c = tid; c < C; c += 256) acc += w[(size_t)o * C + c] * pooled[c];
+    for (int c = cl; c < C; c += 64) acc += w[(size_t)o * C + c] * pooled[c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) out[(size_t)n * O + o] = red[0] + red[1] + red[2] + red[3] + b[o];
-    __syncthreads();
+    if (cl == 0) out[(size_t)n * O + o] = acc + b[o];
   }
 }
 
 int launch_encoder_head(const float* x, const float* scale, const float* shift, const float* w, const float* b, float* out, int N, int HW,
                         int C, int O, hipStream_t s) {
-  hipLaunchKernelGGL(encoder_head_kernel, dim3(N), dim3(256), (C + 4) * sizeof(float), s, x, scale, shift, w, b, out, HW, C, O);
+  DRM_REQUIRE(C % 4 == 0, "encoder head: C % 4");
+  hipLaunchKernelGGL(encoder_head_kernel, dim3(N), dim3(256), (size_t)5 * C * sizeof(float), s, x, scale, shift, w, b, out, HW, C, O);
   DRM_HIP_CHECK(hipGetLastError());
   return DRM_OK;
 }

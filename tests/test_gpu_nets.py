@@ -65,7 +65,10 @@ def test_row_gather_matches_dense(dev):
     rows = torch.tensor([4, 1, 3], dtype=torch.int32, device=dev)
     dense = m.forward_parts(x, c, t_emb=te)
     sub = m.forward_parts(x, c, t_emb=te[rows.long()].contiguous(), rows=rows)
-    assert rel_l2(sub.cpu(), dense[rows.long()].cpu()) < 1e-6
+    e = rel_l2(sub.cpu(), dense[rows.long()].cpu())
+    print(f"row gather (3 of 5 rows) vs the dense batch: {e:.2e}")
+    # (not bit-equal: a batch of <= 4 rows runs its emb linears on the wave-per-feature kernel, larger ones on the matrix-core form -- another fp32 summation order)
+    assert e < 5e-6
 
 
 def full_inputs(n, h, w):

@@ -14,7 +14,10 @@ def man(cin, cout):
          ("out_layers.3.weight", (cout, cout, 3, 3)), ("out_layers.3.bias", (cout,))]
     if cin != cout: m += [("skip_connection.weight", (cout, cin, 1, 1)), ("skip_connection.bias", (cout,))]
     return m
-for (n, cin, cout, h, w) in [(32, 128, 128, 128, 256), (32, 256, 256, 64, 128)]:
+SHAPES = [(32, 128, 128, 128, 256), (32, 256, 256, 64, 128)]
+if os.environ.get("LAYER_SHAPES"):  # "n,cin,cout,h,w;..." (e.g. the batch-1 step's levels: 1,128,128,128,128;1,256,256,64,64)
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["LAYER_SHAPES"].split(";")]
+for (n, cin, cout, h, w) in SHAPES:
     P = [p.to(dev) for p in synth.synth_state_dict(man(cin, cout), 1).values()]
     g = torch.Generator().manual_seed(0)
     x = torch.randn((n, cin, h, w), generator=g).to(dev); emb = torch.randn((n, 512), generator=g).to(dev)
