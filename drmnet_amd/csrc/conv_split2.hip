@@ -256,6 +256,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   float4* Bs = lds + C::A_F4;                                         // R x TPS x [hl 2][s 2][h 2][BN]
   double* lst = reinterpret_cast<double*>(lds + C::A_F4 + R * C::G_F4);  // [TN][BN][2]
 
+#ifndef DRM_NO_KERNARG_TOUCH
+  {
+    // The descriptor is six 64-byte lines of kernel arguments, and under this kernel's SGPR pressure the compiler fetches (and re-fetches) its
+    // fields one s_load round trip at a time all along the prologue: on a sparse launch every first touch of a line is a serial miss.  One
+    // dword of every line is requested here, all at once, so the later loads hit the scalar cache.
+    typedef const __attribute__((address_space(4))) int* kptr_t;
+    kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    int touch = 0;
+#pragma unroll
+    for (int o = 0; o < (int)sizeof(ConvArgs); o += 64) touch ^= __builtin_nontemporal_load(ka + o / 4);
+    asm volatile("" ::"s"(touch));
+  }
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1323,11 +1336,7 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 1, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
   }
-#ifdef DRM_S2_RG_SPARSE
-  constexpr int RS = (TAPS == 9) ? DRM_S2_RG_SPARSE : RG;
-#else
-  constexpr int RS = RG;
-#endif
+  constexpr int RS = RG;  // ([r4] a ring of 4 three-tap groups on these sparse-launch tiles: 5.31 vs 5.38 ms on the batch-1 step, later 5.06 vs 5.08 -- not adopted)
   if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RS, TPS, TERMS>(a, s);
   if (a.ksplit > 1 && a.split_ws) return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RS, TPS, TERMS, false, true>(a, s);  // (conv_split_ksplit: only ever here)
   return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RS, TPS, TERMS>(a, s);
@@ -1370,7 +1379,11 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
 // slab order and runs the full epilogue (SK instantiation; the hand-off costs ~10 us whatever the shape).  Smaller maps: splitk_reduce_small_kernel
 // in a second launch (5.8 us on the 4x8 maps of the batch-32 step, where the fused finish measured 1 % slower on the whole step; at batch 1 the maps
 // of 128 .. 1024 pixels are where the second launch cost 12 .. 22 us: 6.64 -> 6.0 ms per step with the fused finish).
+#ifdef DRM_SK_ALWAYS_FUSED
+bool conv_split_fused_finish(const ConvArgs& a) { return true; }
+#else
 bool conv_split_fused_finish(const ConvArgs& a) { return a.H * a.W >= 128; }
+#endif
 
 // Split-K factor for a launch (1 = none).  Mirrors dispatch_s2_bn: only the 128-row x 32-channel fallback tiles qualify, when
 // their grid leaves most of the 256 CUs idle and the reduction is long.
@@ -1385,6 +1398,7 @@ int conv_split_ksplit(const ConvArgs& a) {
   if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return 1;
   const long long tiles = wgs(128, 32);
   const int nch = (a.C0 + a.C1) / 32;
+  // ([r4] with the cheaper hand-off: splits of >= 2 chunks up to 1024 workgroups measured 5.13 vs 5.08 ms on the batch-1 step -- not adopted)
   const long long ks = std::min<long long>(std::min<long long>(8, nch / 4), 640 / std::max<long long>(tiles, 1));
   return (int)std::max<long long>(ks, 1);
 }

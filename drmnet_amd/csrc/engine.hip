@@ -478,7 +478,9 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   const bool flash = c.split() && attention_flash_applicable(T, C, c.terms());  // the long-sequence level: one kernel, no score matrix (attn_flash.hip)
   float* scores = flash ? nullptr : c.ar->alloc<float>(attention_scores_floats(c.N, T));  // one image group at a time (attn.hip attention_group)
   float* att = c.ar->alloc<float>((size_t)c.N * T * C);
-  const bool on_conv = flash || (c.split() && attention_conv_applicable(T, C, H, W, c.terms()));  // the T >= 512 levels: both GEMMs on the conv pipeline
+  // the T >= 256 levels: both GEMMs on the conv pipeline -- except on sparse launches (the 16x16 level of a batch-1 step: six launches, 51 us, where
+  // the short-sequence form -- qk_small, softmax, P v -- takes three and ~25 us)
+  const bool on_conv = flash || (c.split() && attention_conv_applicable(T, C, H, W, c.terms()) && (long long)c.N * T > 1024);
   float* aws = flash ? c.ar->alloc<float>(attention_flash_workspace_floats(c.N, T, C)) : on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C)) : nullptr;
   ConvArgs p;  // proj_out: 1x1 conv on the raw attention output, a convex combination of v rows: max |att| <= max |v|
   float* wsq = plan_splitk(c, a);
