@@ -151,7 +151,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, float4&
 template <bool BT, int TERMS>
 __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm, int M,
                                                        int Ncols, int K, int lda, int ldb, int ldc, long long sA, long long sB, long long sC,
-                                                       float alpha, float a_scale) {
+                                                       float alpha, float a_scale, const float* __restrict__ b_scale_img = nullptr,
+                                                       const float* __restrict__ alpha_img = nullptr) {
+  // b_scale_img / alpha_img: optional per-image (blockIdx.z) power-of-two staging factor of B and its inverse (the range guard of v: attn_scales_kernel)
+  const float b_scale = b_scale_img ? b_scale_img[blockIdx.z] : 1.0f;
+  if (alpha_img) alpha *= alpha_img[blockIdx.z];
   __shared__ float4 As[2 * 4 * 64];  // [hl][octet of the 32-wide K chunk][row]
   __shared__ float4 Bs[2 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
         const float4 x = p[0], y = p[1];
         v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
       }
-      if (TERMS == 4) round8_bf16(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
-      else split8(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+      if (TERMS == 4) round8_bf16(v, b_scale, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+      else split8(v, b_scale, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
     } else {
       const int oct = tid >> 6, col = tid & 63;
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -196,8 +200,8 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = p[(size_t)j * ldb];
       }
-      if (TERMS == 4) round8_bf16(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
-      else split8(v, 1.0f, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+      if (TERMS == 4) round8_bf16(v, b_scale, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
+      else split8(v, b_scale, Bs[oct * 64 + col], Bs[(4 + oct) * 64 + col]);
     }
     __syncthreads();
 #pragma unroll
@@ -235,7 +239,13 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
 constexpr int QK_UNR = 4;
 template <int TERMS>
 __global__ __launch_bounds__(256) void qk_small_kernel(const float* __restrict__ Q, const float* __restrict__ Kp, float* __restrict__ S, int T, int C,
-                                                       int ld, long long sQ, long long sS, float alpha) {
+                                                       int ld, long long sQ, long long sS, float alpha, const float* __restrict__ q_scale,
+                                                       const float* __restrict__ k_scale, const float* __restrict__ qk_inv,
+                                                       const float* __restrict__ k_inv) {
+  // q_scale .. k_inv: optional per-image (blockIdx.z) power-of-two staging factors of q and k and their inverses (qk_inv carries alpha): the
+  // range guard of attn_scales_kernel, as on the conv-pipeline form
+  const float sq_img = q_scale ? q_scale[blockIdx.z] : 1.0f, sk_img = q_scale ? k_scale[blockIdx.z] : 1.0f;
+  if (q_scale) alpha = qk_inv[blockIdx.z] * k_inv[blockIdx.z];
   __shared__ float part[4][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -274,12 +284,12 @@ __global__ __launch_bounds__(256) void qk_small_kernel(const float* __restrict__
         }
         AF4H8 ah, al, bh, bl;
         if (TERMS == 4) {
-          round8_bf16(qv, 1.0f, ah.f4, al.f4);
-          round8_bf16(kv, 1.0f, bh.f4, bl.f4);
+          round8_bf16(qv, sq_img, ah.f4, al.f4);
+          round8_bf16(kv, sk_img, bh.f4, bl.f4);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.b8, bh.b8, acc, 0, 0, 0);
         } else {
-          split8(qv, 1.0f, ah.f4, al.f4);
-          split8(kv, 1.0f, bh.f4, bl.f4);
+          split8(qv, sq_img, ah.f4, al.f4);
+          split8(kv, sk_img, bh.f4, bl.f4);
           if (TERMS == 3) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h8, bh.h8, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bl.h8, acc, 0, 0, 0);
@@ -581,7 +591,17 @@ int launch_attention_conv(const float* qkv, const double2* qkv_mom, float* score
   return DRM_OK;
 }
 
-int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms) {
+size_t attention_small_workspace_floats(int N, int T, int C) {
+  const size_t Z = (size_t)(C > T ? C : T);
+  return (size_t)N * (2 * C + T + Z) + 7 * (size_t)N + 64;
+}
+
+// Short-sequence form (T <= 256 off the conv pipeline, and every level of a sparse launch): S by qk_small_kernel, row softmax, P v by the 64x64-tile
+// GEMM.  qkv_mom + ws (attention_small_workspace_floats): the split modes stage q, k and v through their per-image powers of two (attn_scales_kernel --
+// the same range guard as the conv-pipeline form: |v| or |q| beyond fp16's range is exact), and proj_guard receives the guard tables of proj_out's
+// input (|attention output| <= max |v|) from the same launch.
+int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms, const double2* qkv_mom, float* ws,
+                     ConvArgs* proj_guard) {
   bool split = terms != 0;
   DRM_REQUIRE(C % 4 == 0 && T > 0 && N > 0, "attention shape");
   const float alpha = 1.0f / sqrtf((float)C);  // (C^-1/4)^2, applied once to the dot product
@@ -592,31 +612,51 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
   // the exact-fp32 form for P v and takes the split form for S like every other level
   const bool split_qk = split && (C % 32 == 0);
   split = split_qk && (T % 32 == 0);
+  const bool guard = split_qk && qkv_mom && ws;
+  float *q_scale = nullptr, *k_scale = nullptr, *qk_inv = nullptr, *k_inv = nullptr, *v_scale = nullptr, *v_inv = nullptr;
+  if (guard) {
+    const size_t Z = (size_t)(C > T ? C : T);
+    float* q_tab = ws;                        // [N][C]
+    float* p_tab = q_tab + (size_t)N * C;     // [N][T]
+    float* zero_tab = p_tab + (size_t)N * T;  // [N][max(C, T)]
+    float* o_tab = zero_tab + (size_t)N * Z;  // [N][C]
+    float* vec = o_tab + (size_t)N * C;       // 7 x [N]
+    qk_inv = vec; k_scale = vec + N; k_inv = vec + 2 * N; float* pv_inv = vec + 3 * N; v_scale = vec + 4 * N; v_inv = vec + 5 * N; q_scale = vec + 6 * N;
+    hipLaunchKernelGGL(attn_scales_kernel, dim3(N), dim3(256), 0, s, qkv_mom, C, T, alpha, q_tab, p_tab, zero_tab, qk_inv, k_scale, k_inv, pv_inv, v_scale,
+                       v_inv, o_tab, q_scale);
+    DRM_HIP_CHECK(hipGetLastError());
+    if (proj_guard) {
+      proj_guard->gn_scale = o_tab;
+      proj_guard->gn_shift = zero_tab;
+      proj_guard->in_inv = v_inv;
+    }
+  }
   const int NB = attention_group(N, T), t32 = (T + 31) / 32;
   const long long sq = (long long)T * 3 * C;  // image stride of qkv
+  auto at = [&](float* p, int n0) { return p ? p + n0 : nullptr; };
   for (int n0 = 0; n0 < N; n0 += NB) {
     const int nb = std::min(NB, N - n0);
     const float* qg = qkv + (size_t)n0 * sq;
     float* og = out + (size_t)n0 * T * C;
     if (split_qk && terms == 4)
-      hipLaunchKernelGGL(qk_small_kernel<4>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha);
+      hipLaunchKernelGGL(qk_small_kernel<4>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha, at(q_scale, n0), at(k_scale, n0), at(qk_inv, n0), at(k_inv, n0));
     else if (split_qk && terms == 1)
-      hipLaunchKernelGGL(qk_small_kernel<1>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha);
+      hipLaunchKernelGGL(qk_small_kernel<1>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha, at(q_scale, n0), at(k_scale, n0), at(qk_inv, n0), at(k_inv, n0));
     else if (split_qk)
-      hipLaunchKernelGGL(qk_small_kernel<3>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha);
+      hipLaunchKernelGGL(qk_small_kernel<3>, dim3(t32, t32, nb), dim3(256), 0, s, qg, qg + C, scores, T, C, 3 * C, sq, (long long)T * T, alpha, at(q_scale, n0), at(k_scale, n0), at(qk_inv, n0), at(k_inv, n0));
     else
       hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha);
     DRM_HIP_CHECK(hipGetLastError());
     DRM_TRY(launch_softmax_rows(scores, (long long)nb * T, T, s));
     if (split && terms == 4)
       hipLaunchKernelGGL((bgemm64s_kernel<false, 4>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
-                         (long long)T * T, sq, (long long)T * C, 1.0f, 1.0f);
+                         (long long)T * T, sq, (long long)T * C, 1.0f, 1.0f, at(v_scale, n0), at(v_inv, n0));
     else if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
       hipLaunchKernelGGL((bgemm64s_kernel<false, 1>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
-                         (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
+                         (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f, at(v_scale, n0), at(v_inv, n0));
     else if (split)
       hipLaunchKernelGGL((bgemm64s_kernel<false, 3>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
-                         (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f);
+                         (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f, at(v_scale, n0), at(v_inv, n0));
     else
       hipLaunchKernelGGL(bgemm64_kernel<false>, dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
                          (long long)T * T, sq, (long long)T * C, 1.0f);

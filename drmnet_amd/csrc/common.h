@@ -139,7 +139,10 @@ int launch_refmap_mask_make(const float* colors, const float* normals, long long
                             unsigned char* refmask, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_erode_mask(const unsigned char* mask, int H, int W, int k, unsigned char* out, hipStream_t s);
 // terms: 0 = fp32 MFMA, 3 = fp16 hi/lo split, 1 = plain fp16 operands
-int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms = 0);
+// qkv_mom + ws (attention_small_workspace_floats floats): per-image range guard of q, k, v in the split modes; proj_guard then receives proj_out's guard tables
+int launch_attention(const float* qkv, float* scores, float* out, int N, int T, int C, hipStream_t s, int terms = 0, const double2* qkv_mom = nullptr,
+                     float* ws = nullptr, ConvArgs* proj_guard = nullptr);
+size_t attention_small_workspace_floats(int N, int T, int C);
 // split-precision attention core on the fused 1x1 conv pipeline (per-image weights = k, v^T); T = H*W must be a multiple of 256
 bool attention_conv_applicable(int T, int C, int H, int W, int terms);
 // single-kernel form (attn_flash.hip): the long-sequence level (T >= 1024, C = 384), no score matrix in HBM

@@ -199,19 +199,15 @@ __device__ __forceinline__ void gload16x2(f32x4& d0, f32x4& d1, const void* p) {
 __device__ __forceinline__ void tie_regs(f32x4& x0, f32x4& x1) { asm volatile("" : "+v"(x0), "+v"(x1)::"memory"); }
 // Agent-scope accesses of the fused split-K hand-off (sc1: coherent across the 8 XCD-private L2s by themselves, the way relaxed agent-scope atomics
 // are -- LLVM AMDGPU memory model, gfx942 rows "load / store atomic monotonic agent").  The slabs move only through these, so the hand-off needs
-// ordering (s_waitcnt vmcnt(0) before the ticket) but no L2 write-back / invalidate.
-#ifndef DRM_SK_MODE
-#define DRM_SK_MODE 0
-#endif
-#if DRM_SK_MODE == 2
-#define DRM_SK_SC "sc0 sc1"
-#else
-#define DRM_SK_SC "sc1"
-#endif
+// ordering (s_waitcnt vmcnt(0) before the ticket) but no L2 write-back / invalidate: MI355X_MICROARCH.md "Valid forms", first row of its table
+// (one lane of each storing workgroup adds to ONE counter after every storing wave's vmcnt(0) wait and a barrier; the workgroup whose add came
+// last loads after a barrier that lane joins; every store and every load of the bytes is a 16-byte global sc1 access).  Checked on this shape
+// of hand-off by tools/probes/sc1_handoff_probe.hip: 0 stale values in 2 x 400 launches with the splits of a tile on one XCD and on different
+// XCDs (plain accesses without the fences: 358 M stale values across XCDs), 9 / 15 us per launch against 33 / 57 us with the fences.
 // (s_nop 1: a store of more than 8 bytes reads its data registers after issue -- the wait states the compiler inserts before it overwrites them
 //  are invisible to it inside asm; without them the next quad transpose corrupted the slab)
-__device__ __forceinline__ void gstore16_agent(void* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off " DRM_SK_SC "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void gload16_agent(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off " DRM_SK_SC : "=&v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gstore16_agent(void* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void gload16_agent(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void tie_reg(f32x4& x) { asm volatile("" : "+v"(x)::"memory"); }
 
 // 4 x 4 transpose across the four lanes of a quad: in, lane q holds x_k = M[q][k]; out, lane q holds x_k = M[k][q].
@@ -1090,20 +1086,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           S2_STAMP(71);  // ... and complete at agent scope
           __builtin_amdgcn_s_barrier();
-          if (tid == 0) {
-#if DRM_SK_MODE == 1 || DRM_SK_MODE == 3
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+          if (tid == 0)
             s_last_tile = __hip_atomic_fetch_add(a.tile_ticket + (x_start + k_tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ks - 1;
-          }
           __syncthreads();
           S2_STAMP(72);  // ticket drawn
           if (s_last_tile) {
-#if DRM_SK_MODE == 1 || DRM_SK_MODE == 4
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             S2_STAMP(73);
             const int col = wn * 32 + r, co = cur.co0 + col;
             const int cq = cur.co0 + wn * 32 + (r & ~3);
@@ -1337,6 +1324,8 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RG, TPS, TERMS>(a, s);
   }
   constexpr int RS = RG;  // ([r4] a ring of 4 three-tap groups on these sparse-launch tiles: 5.31 vs 5.38 ms on the batch-1 step, later 5.06 vs 5.08 -- not adopted)
+  // ([r4] 128 x 32 tiles from 512 workgroups on -- two workgroups per CU on the batch-1 step's top level instead of one: 4.74 vs 4.755 ms there,
+  //  780 vs 800 steps/s at batch 32 -- not adopted: co-resident workgroups do not hide what a sparse launch waits for)
   if (a.Cout % 64 == 0 && wgs(128, 64) >= 256) return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 1, RS, TPS, TERMS>(a, s);
   if (a.ksplit > 1 && a.split_ws) return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RS, TPS, TERMS, false, true>(a, s);  // (conv_split_ksplit: only ever here)
   return launch_s2<TAPS, TH4, TW4, 4, 1, 1, 1, RS, TPS, TERMS>(a, s);
@@ -1379,11 +1368,8 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
 // slab order and runs the full epilogue (SK instantiation; the hand-off costs ~10 us whatever the shape).  Smaller maps: splitk_reduce_small_kernel
 // in a second launch (5.8 us on the 4x8 maps of the batch-32 step, where the fused finish measured 1 % slower on the whole step; at batch 1 the maps
 // of 128 .. 1024 pixels are where the second launch cost 12 .. 22 us: 6.64 -> 6.0 ms per step with the fused finish).
-#ifdef DRM_SK_ALWAYS_FUSED
-bool conv_split_fused_finish(const ConvArgs& a) { return true; }
-#else
+// ([r4] with the agent-scope hand-off the fused finish was tried on the smaller maps too: batch 1 4.79 vs 4.755 ms, batch 32 759 vs 763 steps/s -- the second launch stays)
 bool conv_split_fused_finish(const ConvArgs& a) { return a.H * a.W >= 128; }
-#endif
 
 // Split-K factor for a launch (1 = none).  Mirrors dispatch_s2_bn: only the 128-row x 32-channel fallback tiles qualify, when
 // their grid leaves most of the 256 CUs idle and the reduction is long.

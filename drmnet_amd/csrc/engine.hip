@@ -481,7 +481,11 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
   // the T >= 256 levels: both GEMMs on the conv pipeline -- except on sparse launches (the 16x16 level of a batch-1 step: six launches, 51 us, where
   // the short-sequence form -- qk_small, softmax, P v -- takes three and ~25 us)
   const bool on_conv = flash || (c.split() && attention_conv_applicable(T, C, H, W, c.terms()) && (long long)c.N * T > 1024);
-  float* aws = flash ? c.ar->alloc<float>(attention_flash_workspace_floats(c.N, T, C)) : on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C)) : nullptr;
+  // (the short-sequence form in the split modes: per-image guard factors + proj_out's guard tables, from one attn_scales launch)
+  const bool small_guard = !on_conv && c.split() && C % 32 == 0;
+  float* aws = flash ? c.ar->alloc<float>(attention_flash_workspace_floats(c.N, T, C))
+               : on_conv ? c.ar->alloc<float>(attention_conv_workspace_floats(c.N, T, C))
+               : small_guard ? c.ar->alloc<float>(attention_small_workspace_floats(c.N, T, C)) : nullptr;
   ConvArgs p;  // proj_out: 1x1 conv on the raw attention output, a convex combination of v rows: max |att| <= max |v|
   float* wsq = plan_splitk(c, a);
   p.C0 = C; p.N = c.N; p.H = H; p.W = W; p.taps = 1; p.Cout = C;
@@ -493,12 +497,12 @@ int run_attention(Ctx& c, const float* Wb, const AttnLayer& l, Act& x, Act& out)
     DRM_TRY(run_conv(c, a, Wb, l.qkv_s, &qkv_act, wsq));
     if (flash) DRM_TRY(launch_attention_flash(qkv, qkv_act.mom, att, aws, c.N, T, C, c.terms(), c.s, &p));
     else if (on_conv) DRM_TRY(launch_attention_conv(qkv, qkv_act.mom, scores, att, aws, c.N, H, W, C, c.terms(), c.s, &p));
-    else DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split() ? c.terms() : 0));
+    else DRM_TRY(launch_attention(qkv, scores, att, c.N, T, C, c.s, c.split() ? c.terms() : 0, small_guard ? qkv_act.mom : nullptr, aws, small_guard ? &p : nullptr));
   } else {
     qkv_act.mom_valid = true;  // sizing pass: the table is filled by the conv epilogue, no stand-alone moments launch
     qkv_act.mom_sums = true;
   }
-  if (!on_conv) DRM_TRY(raw_input_guard(c, p, &qkv_act, 2 * C, 3 * C, nullptr, nullptr, C));  // (the conv-pipeline core hands p its guard tables)
+  if (!on_conv && !small_guard) DRM_TRY(raw_input_guard(c, p, &qkv_act, 2 * C, 3 * C, nullptr, nullptr, C));  // (the attention cores of the split modes hand p its guard tables)
   if (!c.dry()) {
     p.src0 = att;
     p.w = Wb + l.proj_w; p.bias = Wb + l.proj_b; p.res = x.p; p.out = out.p;
