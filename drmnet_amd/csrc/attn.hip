@@ -148,7 +148,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, float4&
   lo = l.f4;
 }
 
-template <bool BT, int TERMS>
+// SM (with BT = false: O = softmax(S) v): A holds raw scores and the row softmax is applied while A is staged -- the workgroup first takes the
+// maximum and the sum of exp of its 64 rows (four lanes per row, whole rows: K = T), then stages expf(s - max) / sum: the arithmetic of
+// softmax_rows_kernel, one launch and one pass over the scores less per attention block of the short-sequence levels.
+template <bool BT, int TERMS, bool SM = false>
 __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm, int M,
                                                        int Ncols, int K, int lda, int ldb, int ldc, long long sA, long long sB, long long sC,
                                                        float alpha, float a_scale, const float* __restrict__ b_scale_img = nullptr,
@@ -170,6 +173,29 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
+  [[maybe_unused]] float row_max = 0.f, row_inv = 0.f;  // SM: of row tid >> 2 (the row this thread stages)
+  if constexpr (SM) {
+    const int row = tid >> 2, part = tid & 3;
+    const bool in = m0 + row < M;
+    const float4* p = reinterpret_cast<const float4*>(A + (size_t)min(m0 + row, M - 1) * lda);
+    float m = -INFINITY;
+    for (int q = part; q < K / 4; q += 4) {
+      const float4 x = p[q];
+      m = fmaxf(fmaxf(m, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+    }
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    float sum = 0.f;
+    for (int q = part; q < K / 4; q += 4) {
+      const float4 x = p[q];
+      sum += (expf(x.x - m) + expf(x.y - m)) + (expf(x.z - m) + expf(x.w - m));
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    row_max = in ? m : 0.f;
+    row_inv = in ? 1.0f / sum : 0.f;
+  }
+
   for (int k0 = 0; k0 < K; k0 += 32) {
     {  // A: one (row, octet) per thread, 32 contiguous bytes
       const int row = tid >> 2, oct = tid & 3;
@@ -178,6 +204,10 @@ __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__
         const float4* p = reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k0 + 8 * oct);
         const float4 x = p[0], y = p[1];
         v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+        if constexpr (SM) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = expf(v[j] - row_max) * row_inv;
+        }
       }
       if (TERMS == 4) round8_bf16(v, a_scale, As[oct * 64 + row], As[(4 + oct) * 64 + row]);
       else split8(v, a_scale, As[oct * 64 + row], As[(4 + oct) * 64 + row]);
@@ -647,15 +677,15 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
     else
       hipLaunchKernelGGL(bgemm64_kernel<true>, dim3(tb, tb, nb), dim3(256), 0, s, qg, qg + C, scores, T, T, C, 3 * C, 3 * C, T, sq, sq, (long long)T * T, alpha);
     DRM_HIP_CHECK(hipGetLastError());
-    DRM_TRY(launch_softmax_rows(scores, (long long)nb * T, T, s));
+    if (!split) DRM_TRY(launch_softmax_rows(scores, (long long)nb * T, T, s));  // (the split P v applies the row softmax while it stages the scores)
     if (split && terms == 4)
-      hipLaunchKernelGGL((bgemm64s_kernel<false, 4>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
+      hipLaunchKernelGGL((bgemm64s_kernel<false, 4, true>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
                          (long long)T * T, sq, (long long)T * C, 1.0f, 1.0f, at(v_scale, n0), at(v_inv, n0));
     else if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
-      hipLaunchKernelGGL((bgemm64s_kernel<false, 1>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
+      hipLaunchKernelGGL((bgemm64s_kernel<false, 1, true>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
                          (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f, at(v_scale, n0), at(v_inv, n0));
     else if (split)
-      hipLaunchKernelGGL((bgemm64s_kernel<false, 3>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
+      hipLaunchKernelGGL((bgemm64s_kernel<false, 3, true>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
                          (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f, at(v_scale, n0), at(v_inv, n0));
     else
       hipLaunchKernelGGL(bgemm64_kernel<false>, dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,

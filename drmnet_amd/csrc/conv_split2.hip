@@ -1102,30 +1102,42 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
             for (int g = 0; g < 4; ++g) ev[g] = a.emb ? a.emb[(size_t)nimg[g] * a.emb_stride + co] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) rv[e] = a.res ? a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co] : 0.f;
+            // 16 agent-scope 16-byte loads in flight per round (they come from memory, ~5k cycles a round -- the stamp timeline): all four row
+            // groups at once when ks <= 4, two at a time beyond
+            auto sum_groups = [&](auto G0c, auto NGc, auto NKc) {
+              constexpr int G0 = decltype(G0c)::value, NGR = decltype(NGc)::value, NK = decltype(NKc)::value;
+              f32x4 t[NGR][NK];
 #pragma unroll
-            for (int g2 = 0; g2 < 4; g2 += 2) {  // two row groups at a time: 2 x ks float4 loads in flight
-              f32x4 t[2][8];
+              for (int gg = 0; gg < NGR; ++gg)
 #pragma unroll
-              for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
+                for (int k = 0; k < NK; ++k)
                   // (always issued, on slab 0 beyond ks: an asm load under a branch leaves its destination to a phi copy that may run before it lands)
-                  gload16_agent(t[gg][k], &a.split_ws[(size_t)(k < ks ? k : 0) * a.split_stride + (pixb[g2 + gg] + (r & 3)) * a.Cout + cq]);
+                  gload16_agent(t[gg][k], &a.split_ws[(size_t)(k < ks ? k : 0) * a.split_stride + (pixb[G0 + gg] + (r & 3)) * a.Cout + cq]);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-              for (int gg = 0; gg < 2; ++gg)
+              for (int gg = 0; gg < NGR; ++gg)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) tie_reg(t[gg][k]);
+                for (int k = 0; k < NK; ++k) tie_reg(t[gg][k]);
 #pragma unroll
-              for (int gg = 0; gg < 2; ++gg) {
+              for (int gg = 0; gg < NGR; ++gg) {
                 f32x4 sacc = t[gg][0];
 #pragma unroll
-                for (int k = 1; k < 8; ++k)
+                for (int k = 1; k < NK; ++k)
                   if (k < ks) { sacc.x += t[gg][k].x; sacc.y += t[gg][k].y; sacc.z += t[gg][k].z; sacc.w += t[gg][k].w; }
-                const int g = g2 + gg;
+                const int g = G0 + gg;
                 v[4 * g] = sacc.x; v[4 * g + 1] = sacc.y; v[4 * g + 2] = sacc.z; v[4 * g + 3] = sacc.w;
                 quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], r);  // back to the accumulator layout: one channel, four pixels
               }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I2 = std::integral_constant<int, 2>;
+            using I4 = std::integral_constant<int, 4>;
+            using I8 = std::integral_constant<int, 8>;
+            if (ks <= 4) {
+              sum_groups(I0{}, I4{}, I4{});
+            } else {
+              sum_groups(I0{}, I2{}, I8{});
+              sum_groups(I2{}, I2{}, I8{});
             }
             S2_STAMP(74);  // slabs summed
             float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
