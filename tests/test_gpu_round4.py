@@ -253,3 +253,62 @@ def test_auto_precision_measures_the_loaded_weights(dev, rule, expect):
         m(xc.to(dev), torch.from_numpy(g["t"])[:2].to(dev))
         assert m.auto_report["chosen"] == "f16mx" == m.precision
     assert m.set_precision("f16x3").auto_report is None  # an explicit mode leaves auto
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 4, second half: the sparse-launch forms (batch-1 step).  AttentionBlock (openaimodel.py:278-333 over QKVAttentionLegacy
+# :365-381) on the short-sequence path -- qk_small_kernel, row softmax inside the P v GEMM, per-image range guard of q / k / v --
+# and the GroupNorm finalisation folded into the consumer conv's prologue (launches of <= 4 images).
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ch,h,w", [(640, 8, 8), (768, 4, 4), (512, 16, 16)])
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_short_sequence_attention_keeps_its_range_guard(dev, ch, h, w, precision):
+    """T = 64, 16 and (sparse launch) 256 with the value rows 3e4 x the usual size (|v| ~ 1e5 > fp16's 65504) and q 30 x / k 1/30 x: the staging
+    powers of two are per image and per operand on this path too.  fp64 oracle; rows of a batch == single runs."""
+    from test_gpu_ops import attn_manifest, block_inputs
+
+    xa, _ = block_inputs(ch, ch, h, w, 2)
+    xa[1] *= 5.0
+    P = synth.synth_state_dict(attn_manifest(ch), 32)
+    w_, b_ = P["qkv.weight"].clone(), P["qkv.bias"].clone()
+    for lo, f in ((0, 30.0), (ch, 1.0 / 30.0), (2 * ch, 3e4)):
+        w_[lo:lo + ch] *= f
+        b_[lo:lo + ch] *= f
+    P["qkv.weight"], P["qkv.bias"] = w_, b_
+    P["proj_out.weight"] = P["proj_out.weight"] * 1e-4
+    with ou.working_dtype(torch.float64):
+        ref = ou.attention_block({"ab." + k: v.double() for k, v in P.items()}, ou.Attn("ab", ch), xa.double())
+    try:
+        ops.set_precision(precision)
+        got = ops.attention_block([p.to(dev) for p in P.values()], xa.to(dev)).cpu()
+        one = ops.attention_block([p.to(dev) for p in P.values()], xa[1:2].contiguous().to(dev)).cpu()
+    finally:
+        ops.set_precision("fp32")
+    e = rel_l2(got - xa, ref - xa.double())  # the residual x is added exactly: the attention branch itself
+    print(f"short-sequence attention {ch} @{h}x{w} ({precision}), v x 3e4, q x 30, k / 30: {e:.2e}")
+    assert torch.isfinite(got).all() and e < 1e-4
+    assert rel_l2(one[0], got[1]) < 1e-6
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16mx"])
+def test_sparse_and_dense_launch_forms_agree(dev, precision):
+    """The same images through the sparse-launch forms (<= 4 images: GroupNorm tables finalised in the conv prologue, short-sequence attention at
+    16x16, wave-per-feature emb linears) and inside a batch of 6 (gn_finalize launches, conv-pipeline attention): the tiny and the full-width
+    IllNet, rows compared pairwise."""
+    from test_gpu_nets import build, full_inputs
+
+    for cfg, kind, shape in ((ou.TINY_UNET_CFG, "unet", (6, 6, 16, 32)), (ou.ILLNET_CFG, "unet", (6, 6, 64, 64))):
+        m = build(cfg, kind, 5, dev)
+        gen = torch.Generator().manual_seed(17)
+        x = torch.randn(shape, generator=gen)
+        te = torch.randn((shape[0], cfg["model_channels"]), generator=gen)
+        try:
+            m.set_precision(precision)
+            dense = m(x.to(dev), t_emb=te.to(dev)).cpu()
+            sparse = torch.cat([m(x[i:i + 2].contiguous().to(dev), t_emb=te[i:i + 2].contiguous().to(dev)).cpu() for i in (0, 2, 4)])
+        finally:
+            m.set_precision("fp32")
+        e = rel_l2(sparse, dense)
+        print(f"sparse vs dense launch forms, {'tiny' if cfg is ou.TINY_UNET_CFG else 'full-width'} IllNet ({precision}): {e:.2e}")
+        # (f16mx: the two forms run other tile families, i.e. two realisations of the mode's ~2e-5 rounding noise; the exact modes differ by summation order only)
+        assert torch.isfinite(dense).all() and e < (NET_TOL["f16mx"] if precision == "f16mx" else 2e-6)
