@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void encoder_head_kernel(const float* __restri
   const int n = blockIdx.x, tid = threadIdx.x;
   // 64 channel lanes x 4 pixel lanes: a thread walks every 4th pixel of its channel (one serial chain of HW dependent loads per
   // thread made this kernel 80 us at HW = 512); the four partial sums of a channel are added in a fixed order.  One barrier for
-  // all channel passes and none in the projection (a wave per output feature): 25 -> 8 us in the batch-1 step.
+  // all channel passes and none in the projection (a wave per output feature): 25 -> 16 us in the batch-1 step.
   const int cl = tid & 63, pl = tid >> 6;
   const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)n * HW * C);
   const float4* sc4 = reinterpret_cast<const float4*>(scale + (size_t)n * C);
