@@ -14,7 +14,9 @@ every rank owns its own `--batch` refmaps; the path has no collective -- samples
 The JSON line carries
   roofline     : dominant kernel = fused GroupNorm+SiLU+conv3x3 implicit GEMM (conv.hip); achieved = algorithmic conv3x3
                  FLOPs of its launches / their summed duration, both measured with HIP events on the launch stream inside the
-                 timed region (library profiler, include/drmnet_hip.h drm_profile_*); peak = 157.3 TFLOP/s fp32 MFMA.
+                 timed region (library profiler, include/drmnet_hip.h drm_profile_*); peak = the dense MFMA peak of the mode;
+                 traffic = HBM bytes per launch of the dominant instantiation from two `rocprofv3 --pmc` child runs of this same
+                 command (FETCH_SIZE, WRITE_SIZE: separate passes), made after the timed region (live_traffic below).
   cpu_baseline : the CPU oracle (oracle/, a port of the reference's arithmetic) timed on this box's host cores on a bounded
                  sample of the same workload (rank 0, N = 1 only).
 Other workloads (--workload illnet | refnet | obsnet | obsnet_ddim) time a single network / sampler for the DESIGN.md tables.
@@ -58,6 +60,7 @@ def parse():
                          "tests/test_gpu_split.py); fp32 = v_mfma_f32_32x32x2_f32; f16 = reduced precision (~1e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic in this run (the committed profile is imported instead, hash-gated)")
     ap.add_argument("--no-strict-fp32", action="store_true", help="skip the short exact-fp32 pass that follows the headline measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (B = 128 / B = 1 steps, ObsNet DDIM chain at B = 256, full chain) that follow it")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the batch-1 parity forward passes (keeps a rocprofv3 trace of this command to the timed workload's launches)")
@@ -307,6 +310,57 @@ def imported_traffic(applicable: bool, precision: str = "f16x3") -> dict:
         out["traffic_source"] = f"imported from {rel} (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch of {DOMINANT_VARIANT}; same kernel source, sha {prof['conv_split2_sha16']})"
         return out
     return out
+
+
+def under_profiler() -> bool:
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_traffic(args, dominant: str, timeout_s: int = 300) -> dict:
+    """roofline.traffic measured IN this run: two child runs of this same script under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: MI355X_MICROARCH.md HBM section), three steps each, started as child processes
+    (never exec'd: this process holds the GPU); per launch of `dominant`: 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 reports half of wide streaming
+    reads).  Returns {} when rocprofv3 is not there, a child fails or its database cannot be read -- the committed profile is imported then."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp) or under_profiler():
+        return {}
+    per_launch = {}
+    try:
+        with tempfile.TemporaryDirectory(prefix="drm_pmc_", dir="/tmp") as td:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(td, ctr)
+                cmd = [rp, "--pmc", ctr, "--kernel-trace", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--precision", args.precision,
+                       "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--steps", "2", "--warmup", "1",
+                       "--no-cpu-baseline", "--no-profile", "--no-parity-check", "--no-strict-fp32", "--no-secondary", "--no-live-traffic"]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+                dbs = sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True))
+                if r.returncode != 0 or not dbs:
+                    return {}
+                con = sqlite3.connect(dbs[-1])
+                cols = [c[1] for c in con.execute("pragma table_info(counters_collection)")]
+                kcol = "kernel_name" if "kernel_name" in cols else [c for c in cols if "kernel" in c and "name" in c][0]
+                total, disp = 0.0, set()
+                for name, d, v in con.execute(f"select {kcol}, dispatch_id, value from counters_collection where counter_name = ?", (ctr,)):
+                    if name.split("(")[0] == dominant:
+                        total += v
+                        disp.add(d)
+                con.close()
+                if not disp:
+                    return {}
+                per_launch[ctr] = (total / len(disp), len(disp))
+    except Exception:  # noqa: BLE001 -- any failure of the side measurement falls back to the committed profile
+        return {}
+    fe, wr = per_launch["FETCH_SIZE"], per_launch["WRITE_SIZE"]
+    return {"traffic": int((2.0 * fe[0] + wr[0]) * 1024), "traffic_kernel": dominant,
+            "traffic_source": (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this command (separate passes, --kernel-trace only; "
+                               f"{fe[1]} / {wr[1]} launches of the dominant variant), 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; raw per launch: "
+                               f"FETCH_SIZE {fe[0]:.1f} KB, WRITE_SIZE {wr[0]:.1f} KB")}
 
 
 def rank_aggregate(dt_local: float, units_local: float, dist=None, device=None):
@@ -712,6 +766,15 @@ def main():
             # ... and it is set against the algorithmic bytes of THE SAME instantiation's launches (the library profiler's per-variant
             # totals of the timed region), not the family mean over all 3x3 variants
             dom = max(timed_variants.items(), key=lambda kv: kv[1]["ms"])[0] if timed_variants else None
+            # [r4] ... and since round 4 it is MEASURED in this run where that is possible (single process, the headline shape): two short
+            # rocprofv3 --pmc child runs of this command; the committed profile stays as the fallback and as a cross-check
+            if (dom is not None and world == 1 and split and args.workload == "drmnet_step" and (args.batch, args.height, args.width) == (32, 128, 256)
+                    and not args.no_live_traffic):
+                live = live_traffic(args, dom)
+                if live.get("traffic") is not None:
+                    if tr.get("traffic") is not None:
+                        live["traffic_committed_profile"] = tr["traffic"]
+                    tr = live
             if dom is not None:
                 dv = timed_variants[dom]
                 dv_ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
@@ -724,7 +787,7 @@ def main():
                     roofline["dominant_variant"]["traffic_ratio"] = round(tr["traffic"] / (dv["bytes"] / dv["launches"]), 3)
             roofline["traffic"] = tr.get("traffic")
             roofline["traffic_is_for"] = "dominant_variant (see that object for the matching algorithmic bytes and the ratio)" if tr.get("traffic") is not None else None
-            for k_ in ("traffic_source", "traffic_note"):
+            for k_ in ("traffic_source", "traffic_note", "traffic_committed_profile"):
                 if k_ in tr:
                     roofline[k_] = tr[k_]
         # the two other matrix families of the step (second, untimed pass: every family instrumented)

@@ -6,7 +6,7 @@ cd "$ROOT"
 for rep in 1 2; do
   for lib in "$@"; do
     if [ "$lib" = "-" ]; then unset DRM_LIB_PATH; else export DRM_LIB_PATH="$ROOT/$lib"; fi
-    python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-parity-check --no-secondary > /tmp/ab.log 2>/dev/null
+    python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-parity-check --no-secondary --no-live-traffic > /tmp/ab.log 2>/dev/null
     echo "[$lib]"; python tools/bsum.py /tmp/ab.log | head -${AB_LINES:-3}
   done
 done

@@ -9,10 +9,10 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/prof_round"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
-python3 bench.py --precision $prec > $OUT/${tag}_bench_${prec}.log 2>&1
+python3 bench.py --precision $prec --no-live-traffic > $OUT/${tag}_bench_${prec}.log 2>&1   # (the PMC passes below are this script's own)
 grep "^{\"metric\"" $OUT/${tag}_bench_${prec}.log | tail -1 > $OUT/${tag}_bench_${prec}.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -- python3 $ROOT/bench.py --precision $prec --steps 5 --warmup 2 --no-cpu-baseline --no-parity-check --no-strict-fp32 --no-secondary > $OUT/${tag}_bench_${prec}_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -- python3 $ROOT/bench.py --precision $prec --steps 5 --warmup 2 --no-cpu-baseline --no-parity-check --no-strict-fp32 --no-secondary --no-live-traffic > $OUT/${tag}_bench_${prec}_under_rocprof.log 2>&1
 grep "^{\"metric\"" $OUT/${tag}_bench_${prec}_under_rocprof.log | tail -1 > $OUT/${tag}_bench_${prec}_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-parity-check --no-strict-fp32 --no-secondary > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -- python3 $ROOT/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-parity-check --no-strict-fp32 --no-secondary > $OUT/pmc_write.log 2>&1

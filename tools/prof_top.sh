@@ -4,7 +4,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 mkdir -p "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$ROOT/gpurun_out/prof_top"
-rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/prof_top" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check --no-strict-fp32 --no-secondary "$@" > "$ROOT/gpurun_out/prof_top.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/prof_top" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check --no-strict-fp32 --no-secondary --no-live-traffic "$@" > "$ROOT/gpurun_out/prof_top.log" 2>&1
 cd "$ROOT"
 python3 - <<'PY'
 import sqlite3, glob
