@@ -150,7 +150,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, float4&
 
 // SM (with BT = false: O = softmax(S) v): A holds raw scores and the row softmax is applied while A is staged -- the workgroup first takes the
 // maximum and the sum of exp of its 64 rows (four lanes per row, whole rows: K = T), then stages expf(s - max) / sum: the arithmetic of
-// softmax_rows_kernel, one launch and one pass over the scores less per attention block of the short-sequence levels.
+// softmax_rows_kernel, one launch and one pass over the scores less per attention block.  (The short-sequence levels have since moved to
+// pv_small_kernel, which applies the softmax the same way with the keys split over the waves of a workgroup; this form stays for callers of the
+// 64x64-tile GEMM.)
 template <bool BT, int TERMS, bool SM = false>
 __global__ __launch_bounds__(256) void bgemm64s_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Cm, int M,
                                                        int Ncols, int K, int lda, int ldb, int ldc, long long sA, long long sB, long long sC,
@@ -337,6 +339,110 @@ __global__ __launch_bounds__(256) void qk_small_kernel(const float* __restrict__
     const int idx = tid + 256 * j, row = idx >> 5, col = idx & 31;
     const float v = ((part[0][row * 33 + col] + part[1][row * 33 + col]) + part[2][row * 33 + col]) + part[3][row * 33 + col];
     if (m0 + row < T && n0 + col < T) S[(size_t)(m0 + row) * T + n0 + col] = alpha * v;
+  }
+}
+
+// O = softmax(S) v of the short-sequence levels, latency form (the counterpart of qk_small_kernel; replaces bgemm64s_kernel<false, ., SM> there:
+// T = 256 took 20 us on 32 workgroups, eight load -> split -> LDS -> barrier -> MFMA rounds each).  A workgroup owns 32 queries x 32 channels;
+// it first takes the maximum and the sum of exp of its 32 score rows (eight lanes per row), then its four waves split the keys: a lane loads
+// eight consecutive scores of "its" row and eight v values of "its" channel per 16-key step straight into the MFMA operand layout, applies
+// expf(s - max) / sum * 2^12 to the scores and the per-image power of two to v (attn_scales_kernel), no LDS and no barrier in the loop; the four
+// partial tiles meet in LDS and are added in wave order (deterministic).
+constexpr int PV_UNR = 2;
+template <int TERMS>
+__global__ __launch_bounds__(256) void pv_small_kernel(const float* __restrict__ S, const float* __restrict__ V, float* __restrict__ O, int T, int C, int ldv,
+                                                       long long sS, long long sV, long long sO, float alpha, float a_scale,
+                                                       const float* __restrict__ v_scale_img, const float* __restrict__ v_inv_img) {
+  __shared__ float part[4][32 * 33];
+  __shared__ float row_max[32], row_inv[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  S += (size_t)blockIdx.z * sS;
+  V += (size_t)blockIdx.z * sV;
+  O += (size_t)blockIdx.z * sO;
+  const float v_scale = v_scale_img ? v_scale_img[blockIdx.z] : 1.0f;
+  if (v_inv_img) alpha *= v_inv_img[blockIdx.z];
+  {  // row softmax statistics: row = tid >> 3, eight lanes per row over whole rows (T % 32 == 0)
+    const int row = tid >> 3, part8 = tid & 7;
+    const float4* p = reinterpret_cast<const float4*>(S + (size_t)min(m0 + row, T - 1) * T);
+    float m = -INFINITY;
+    for (int q = part8; q < T / 4; q += 8) {
+      const float4 x = p[q];
+      m = fmaxf(fmaxf(m, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+    }
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    m = fmaxf(m, __shfl_xor(m, 4));
+    float sum = 0.f;
+    for (int q = part8; q < T / 4; q += 8) {
+      const float4 x = p[q];
+      sum += (expf(x.x - m) + expf(x.y - m)) + (expf(x.z - m) + expf(x.w - m));
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    if (part8 == 0) {
+      row_max[row] = m;
+      row_inv[row] = 1.0f / sum;
+    }
+  }
+  __syncthreads();
+  const bool qin = m0 + r < T, cin = c0 + r < C;
+  const float rm = row_max[r], ri = qin ? row_inv[r] * a_scale : 0.f;
+  const int steps = T / 16, per = (steps + 3) / 4;
+  const int s0 = wave * per, s1 = min(steps, s0 + per);
+  const float4* sp = reinterpret_cast<const float4*>(S + (size_t)min(m0 + r, T - 1) * T + 8 * h);
+  const float* vp = V + (size_t)(8 * h) * ldv + min(c0 + r, C - 1);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int sb = s0; sb < s1; sb += PV_UNR) {
+    float4 sa[PV_UNR][2];
+    float va[PV_UNR][8];
+#pragma unroll
+    for (int u = 0; u < PV_UNR; ++u) {
+      const int st = min(sb + u, s1 - 1);  // (a step past the range re-reads the last one and is not accumulated)
+      sa[u][0] = sp[4 * st];
+      sa[u][1] = sp[4 * st + 1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) va[u][j] = vp[(size_t)(16 * st + j) * ldv];
+    }
+#pragma unroll
+    for (int u = 0; u < PV_UNR; ++u) {
+      if (sb + u < s1) {
+        float pv[8] = {sa[u][0].x, sa[u][0].y, sa[u][0].z, sa[u][0].w, sa[u][1].x, sa[u][1].y, sa[u][1].z, sa[u][1].w};
+        float vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pv[j] = expf(pv[j] - rm) * ri;
+          vv[j] = cin ? va[u][j] : 0.f;
+        }
+        AF4H8 ah, al, bh, bl;
+        if (TERMS == 4) {
+          round8_bf16(pv, 1.0f, ah.f4, al.f4);
+          round8_bf16(vv, v_scale, bh.f4, bl.f4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.b8, bh.b8, acc, 0, 0, 0);
+        } else {
+          split8(pv, 1.0f, ah.f4, al.f4);
+          split8(vv, v_scale, bh.f4, bl.f4);
+          if (TERMS == 3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h8, bh.h8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bl.h8, acc, 0, 0, 0);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h8, bh.h8, acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[wave][((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[e];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j, row = idx >> 5, col = idx & 31;
+    const float v = ((part[0][row * 33 + col] + part[1][row * 33 + col]) + part[2][row * 33 + col]) + part[3][row * 33 + col];
+    if (m0 + row < T && c0 + col < C) O[(size_t)(m0 + row) * C + c0 + col] = alpha * v;
   }
 }
 
@@ -679,14 +785,14 @@ int launch_attention(const float* qkv, float* scores, float* out, int N, int T, 
     DRM_HIP_CHECK(hipGetLastError());
     if (!split) DRM_TRY(launch_softmax_rows(scores, (long long)nb * T, T, s));  // (the split P v applies the row softmax while it stages the scores)
     if (split && terms == 4)
-      hipLaunchKernelGGL((bgemm64s_kernel<false, 4, true>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
-                         (long long)T * T, sq, (long long)T * C, 1.0f, 1.0f, at(v_scale, n0), at(v_inv, n0));
+      hipLaunchKernelGGL(pv_small_kernel<4>, dim3((C + 31) / 32, t32, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, 3 * C, (long long)T * T, sq,
+                         (long long)T * C, 1.0f, 1.0f, at(v_scale, n0), at(v_inv, n0));
     else if (split && terms == 1)  // probabilities are scaled by 2^12 before the fp16 conversion (largest 4096, smallest normal 2^-26)
-      hipLaunchKernelGGL((bgemm64s_kernel<false, 1, true>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
-                         (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f, at(v_scale, n0), at(v_inv, n0));
+      hipLaunchKernelGGL(pv_small_kernel<1>, dim3((C + 31) / 32, t32, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, 3 * C, (long long)T * T, sq,
+                         (long long)T * C, 1.0f / 4096.0f, 4096.0f, at(v_scale, n0), at(v_inv, n0));
     else if (split)
-      hipLaunchKernelGGL((bgemm64s_kernel<false, 3, true>), dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
-                         (long long)T * T, sq, (long long)T * C, 1.0f / 4096.0f, 4096.0f, at(v_scale, n0), at(v_inv, n0));
+      hipLaunchKernelGGL(pv_small_kernel<3>, dim3((C + 31) / 32, t32, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, 3 * C, (long long)T * T, sq,
+                         (long long)T * C, 1.0f / 4096.0f, 4096.0f, at(v_scale, n0), at(v_inv, n0));
     else
       hipLaunchKernelGGL(bgemm64_kernel<false>, dim3((C + 63) / 64, tb, nb), dim3(256), 0, s, scores, qg + 2 * C, og, T, C, T, T, 3 * C, C,
                          (long long)T * T, sq, (long long)T * C, 1.0f);
