@@ -135,3 +135,44 @@ def test_a_failing_rank_ends_the_job_with_rc_and_no_result_line(tmp_path, capfd)
     rc = bench.self_launch(argparse.Namespace(gpus=2), command=[sys.executable, str(child), "ok"], have=2, poll_s=0.05)
     out = capfd.readouterr()
     assert rc == 0 and out.out.count('"metric"') == 1
+
+
+def test_live_traffic_falls_back_quietly(monkeypatch):
+    """bench.py measures roofline.traffic with two rocprofv3 --pmc child runs of its own command; where that cannot be done -- no rocprofv3, the
+    run is itself under the profiler, a child fails -- it returns {} and the committed (hash-gated) profile is imported instead."""
+    import argparse
+    import shutil
+    import subprocess
+
+    import bench
+
+    args = argparse.Namespace(precision="auto", batch=32, height=128, width=256)
+    dom = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 2, false, false>"
+    # under a profiler: no nested rocprofv3
+    monkeypatch.setenv("ROCPROFILER_REGISTER_FORCE_LOAD", "1")
+    assert bench.under_profiler() and bench.live_traffic(args, dom) == {}
+    monkeypatch.delenv("ROCPROFILER_REGISTER_FORCE_LOAD")
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_")):
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("LD_PRELOAD", "")
+    assert not bench.under_profiler()
+    # no rocprofv3 on the box
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    real_exists = os.path.exists
+    monkeypatch.setattr(os.path, "exists", lambda p: False if p.endswith("rocprofv3") else real_exists(p))
+    assert bench.live_traffic(args, dom) == {}
+    # a child run that fails (no GPU here): rc != 0 -> {}
+    monkeypatch.setattr(os.path, "exists", real_exists)
+    monkeypatch.setattr(shutil, "which", lambda name: "/bin/false" if name == "rocprofv3" else None)
+    calls = []
+    real_run = subprocess.run
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        return real_run(["/bin/false"], **{k: v for k, v in kw.items() if k in ("stdout", "stderr", "timeout")})
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    assert bench.live_traffic(args, dom) == {}
+    assert calls and "--pmc" in calls[0] and "FETCH_SIZE" in calls[0] and "--no-live-traffic" in calls[0] and "--kernel-trace" in calls[0]
+    assert not any(f in calls[0] for f in ("--sys-trace", "-s", "--runtime-trace", "-r", "--hip-trace"))  # (counters in their own pass: the pool's rule)
