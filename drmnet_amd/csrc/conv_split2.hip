@@ -75,8 +75,7 @@ constexpr float MX_A_LIM = 3584.0f;
 constexpr float MX_AH_DIV = 8.0f;                // ah8 = v / 2^(EA-8)
 constexpr float MX_AL_DIV = 1.0f / 256.0f;       // al8 = (v - ah) / 2^(EA-19)   (|v - ah| <= 2^(EA-11))
 constexpr int MX_SA_AL = 127 + MX_EA - 19, MX_SA_AH = 127 + MX_EA - 8;  // E8M0 factors of A's two blocks
-constexpr float MX_BH_DIV = 64.0f;               // bh8 = bh / 2^6 (|bh| < 2^14), bl8 = bl * 2^6 (|bl| <= 4)
-constexpr float MX_BL_DIV = 1.0f / 64.0f;
+// (weights: bh8 = bh / 2^6 (|bh| < 2^14), bl8 = bl * 2^6 (|bl| <= 4), packed by pack_conv_weight_mx_kernel)
 constexpr int MX_SB_BH = 127 + 6, MX_SB_BL = 127 - 6;
 
 template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3>
@@ -1298,6 +1297,28 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
 
 constexpr long long S2_MIN_WIDE_TILES = 176;  // 256 x 128 tiles are used from this many workgroups on (of 256 CUs)
 
+// Deep levels (maps of at most 128 pixels: the 8x16 and 4x8 levels of a batch-32 step): too few GEMM rows for the 128-channel-wide tiles to fill
+// the chip, and the narrow tiles that do fill it re-stage (GroupNorm + SiLU + split) every activation tile once per 32 or 64 output channels.
+// Split-K over the WIDE tiles instead: every split writes its slab, splitk_reduce_small_kernel finishes (two-launch form).  Returns the
+// split factor (1 = not this form).
+inline int conv_split_wide_ksplit(const ConvArgs& a) {
+#ifdef DRM_NO_WIDE_SPLIT
+  return 1;
+#else
+  if (a.taps != 9 || a.out_nchw || a.w_img_stride_f4 != 0 || a.Cout % 128 != 0) return 1;
+  const int hw = a.H * a.W;
+  if (hw > 128 || !((a.H % 8 == 0 && a.W % 16 == 0) || (a.H % 4 == 0 && a.W % 8 == 0))) return 1;
+  const long long rows = (long long)a.N * hw;
+  if (rows < 1024) return 1;  // (sparse launches keep the narrow tiles: a batch-1 step would fill half a wide tile)
+  const int bm = (a.H % 8 == 0 && a.W % 16 == 0) ? 256 : 128;  // (4x8 maps: 128-pixel x 128-channel tiles on 4 waves, dispatch_s2_bn)
+  const long long tiles = ((rows + bm - 1) / bm) * (a.Cout / 128);
+  if (tiles >= S2_MIN_WIDE_TILES) return 1;
+  const int nch = (a.C0 + a.C1) / 32;
+  const long long ks = std::min<long long>(std::min<long long>(8, nch / 2), std::max<long long>(1, 256 / tiles));
+  return (int)std::max<long long>(ks, 1);
+#endif
+}
+
 // 256-pixel x {128, 64}-channel tiles on 8 waves, 128-pixel x {64, 32}-channel tiles on 4 waves
 template <int TAPS, int TH, int TW, int TH4, int TW4, int TERMS>
 static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
@@ -1327,7 +1348,7 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     // the scalar-base DMA addressing took the kernel from 256 to 207 VGPRs.
     if (a.Cout % 192 == 0 && wgs(256, 192) >= 512) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
   }
-  if (a.Cout % 128 == 0 && wgs(256, 128) >= S2_MIN_WIDE_TILES) {
+  if (a.Cout % 128 == 0 && (wgs(256, 128) >= S2_MIN_WIDE_TILES || (a.ksplit > 1 && !a.split_ws && conv_split_wide_ksplit(a) > 1))) {
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
   }
@@ -1356,7 +1377,7 @@ static int dispatch_s2_ragged(const ConvArgs& a, hipStream_t s) {
 static bool s2_exact(const ConvArgs& a) { return a.H % 4 == 0 && a.W % 4 == 0; }
 
 template <int TAPS, int TERMS>
-static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
+int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
   if (a.H % 16 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 16, 16, 8, 16, TERMS>(a, s);
   if (a.H % 8 == 0 && a.W % 16 == 0) return dispatch_s2_bn<TAPS, 8, 16, 8, 16, TERMS>(a, s);
   if (a.H % 8 == 0 && a.W % 8 == 0) return dispatch_s2_bn<TAPS, 8, 8, 8, 8, TERMS>(a, s);
@@ -1376,17 +1397,33 @@ static int dispatch_s2_tile(const ConvArgs& a, hipStream_t s) {
   }
 }
 
+// Build units: this file is compiled once per (TAPS, TERMS) pair with -DDRM_S2_UNIT=<10 * TAPS + TERMS> (the kernel instantiations of that pair,
+// in parallel: drmnet_amd/build.py) and once without (the host-side rest below, which only declares them).
+#ifdef DRM_S2_UNIT
+template int dispatch_s2_tile<DRM_S2_UNIT / 10, DRM_S2_UNIT % 10>(const ConvArgs&, hipStream_t);
+#else
+extern template int dispatch_s2_tile<9, 0>(const ConvArgs&, hipStream_t);
+extern template int dispatch_s2_tile<1, 0>(const ConvArgs&, hipStream_t);
+extern template int dispatch_s2_tile<9, 1>(const ConvArgs&, hipStream_t);
+extern template int dispatch_s2_tile<1, 1>(const ConvArgs&, hipStream_t);
+extern template int dispatch_s2_tile<9, 4>(const ConvArgs&, hipStream_t);
+extern template int dispatch_s2_tile<1, 4>(const ConvArgs&, hipStream_t);
+extern template int dispatch_s2_tile<9, 2>(const ConvArgs&, hipStream_t);
+extern template int dispatch_s2_tile<9, 3>(const ConvArgs&, hipStream_t);
+extern template int dispatch_s2_tile<1, 3>(const ConvArgs&, hipStream_t);
+
 // Who finishes a split-K conv.  Maps of at least 128 pixels: the launch itself -- the workgroup that arrives last at an output tile sums the slabs in
 // slab order and runs the full epilogue (SK instantiation; the hand-off costs ~10 us whatever the shape).  Smaller maps: splitk_reduce_small_kernel
 // in a second launch (5.8 us on the 4x8 maps of the batch-32 step, where the fused finish measured 1 % slower on the whole step; at batch 1 the maps
 // of 128 .. 1024 pixels are where the second launch cost 12 .. 22 us: 6.64 -> 6.0 ms per step with the fused finish).
 // ([r4] with the agent-scope hand-off the fused finish was tried on the smaller maps too: batch 1 4.79 vs 4.755 ms, batch 32 759 vs 763 steps/s -- the second launch stays)
-bool conv_split_fused_finish(const ConvArgs& a) { return a.H * a.W >= 128; }
+bool conv_split_fused_finish(const ConvArgs& a) { return a.H * a.W >= 128 && conv_split_wide_ksplit(a) <= 1; }
 
 // Split-K factor for a launch (1 = none).  Mirrors dispatch_s2_bn: only the 128-row x 32-channel fallback tiles qualify, when
 // their grid leaves most of the 256 CUs idle and the reduction is long.
 int conv_split_ksplit(const ConvArgs& a) {
   if (a.out_nchw || !s2_exact(a) || a.w_img_stride_f4 != 0) return 1;
+  if (const int wide = conv_split_wide_ksplit(a); wide > 1) return wide;
   // (1x1 convs too [r3]: on the deep, small maps a K = 768 .. 1536 reduction is 24 .. 48 serial one-chunk steps of a handful of workgroups --
   //  30 us at batch 1 whatever the map; split, they are ~5 chunks each plus the small-map reduction)
   const long long rows = (long long)a.N * a.H * a.W;
@@ -1491,5 +1528,6 @@ int launch_conv_split2(const ConvArgs& a, hipStream_t s) {
   if (a.taps == 9) return dispatch_s2_tile<9, 3>(a, s);
   return dispatch_s2_tile<1, 3>(a, s);
 }
+#endif  // DRM_S2_UNIT
 
 }  // namespace drm

@@ -5,16 +5,11 @@
 set -e
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$ROOT"
-mkdir -p gpurun_out /tmp/drm_stamp_obj
+mkdir -p gpurun_out
 OUT="${1:-$ROOT/gpurun_out/stamps.txt}"
+PREC="${2:-f16mx}"
 : > "$OUT"
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=off -DDRM_S2_STAMP"
-objs=""
-for f in conv conv_split conv_split2 gn attn misc refmap transform engine samplers abi profiler; do
-  hipcc $FLAGS -c drmnet_amd/csrc/$f.hip -o /tmp/drm_stamp_obj/$f.o &
-  objs="$objs /tmp/drm_stamp_obj/$f.o"
-done
-wait
-hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/libdrmnet_hip_stamp.so $objs
-DRM_LIB_PATH=/tmp/libdrmnet_hip_stamp.so DRM_S2_STAMP_FILE="$OUT" python3 tools/layer_probe.py f16x3
+# (every source: -DDRM_S2_STAMP adds fields to ConvArgs; built here or beforehand in the build container -- the .so travels with gpurun)
+[ -f drmnet_amd/csrc/_ab/libdrmnet_hip_stamp.so ] || python -m drmnet_amd.build --variant stamp --flags=-DDRM_S2_STAMP --srcs all
+DRM_LIB_PATH="$ROOT/drmnet_amd/csrc/_ab/libdrmnet_hip_stamp.so" DRM_S2_STAMP_FILE="$OUT" python3 tools/layer_probe.py $PREC
 echo "wrote $OUT"
