@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libdrmnet_hip.so")
-SOURCES = ["conv.hip", "conv_split.hip", "conv_split2.hip", "gn.hip", "attn.hip", "attn_flash.hip", "misc.hip", "refmap.hip", "transform.hip", "engine.hip", "samplers.hip", "abi.hip", "profiler.hip"]
+SOURCES = ["conv.hip", "conv_split.hip", "conv_split2.hip", "gn.hip", "attn.hip", "attn_flash.hip", "misc.hip", "stemhead.hip", "refmap.hip", "transform.hip", "engine.hip", "samplers.hip", "abi.hip", "profiler.hip"]
 # conv_split2.hip is also compiled once per (TAPS, TERMS) pair of its kernel template (-DDRM_S2_UNIT=10 * TAPS + TERMS): nine objects built in
 # parallel instead of one 4.5-minute translation unit; the plain compile above holds the host-side rest
 S2_UNITS = [92, 93, 13, 90, 10, 91, 11, 94, 14]  # (slowest first)

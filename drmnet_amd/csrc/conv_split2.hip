@@ -774,10 +774,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         const bool n1 = (chunk + 1 < nchunks) || has_next;                      // a next step exists
         const bool n2 = (chunk + 2 < nchunks) || (has_next && nchunks >= 2);    // ... and one after it (persistent mode needs nchunks >= 2)
         auto side = [&]() {
+          S2_STAMP(40);  // side work starts
           if (n1) {
             if (step == 0) wait_vmcnt<0>();       // first step: the request is the youngest operation
             else wait_vmcnt<C::G_PER>();          // younger: the weight group issued right after it
+            S2_STAMP(41);  // next step's activations landed
             store_A(As + ((step + 1) & 1) * C::A1_F4);  // the buffer read one step ago: every wave passed that barrier
+            S2_STAMP(42);  // ... and are staged
           }
           if (n2) {
             if (chunk + 2 < nchunks) load_A(cur, chunk + 2);
@@ -785,15 +788,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           }
           issue_ahead(chunk);
         };
+        S2_STAMP(2);
         if (!y_first) side();
         mma_tap(As + (step & 1) * C::A1_F4, Bs + (step % R) * C::G_F4, 0, [](int) {});
+        S2_STAMP(3);
         if (y_first) side();
         ++step;
         // (ring of 2: the group the next step reads was issued in THIS step, after the activation request: nothing may stay in flight)
         if (n2 && R > 2) wait_vmcnt<BASE + C::A_CNT>();
         else wait_vmcnt<BASE>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        S2_STAMP(7);
         __builtin_amdgcn_s_barrier();
+        S2_STAMP(8);
       }
     } else {
     const int nch_run = nchunks;
@@ -1305,12 +1312,14 @@ inline int conv_split_wide_ksplit(const ConvArgs& a) {
 #ifdef DRM_NO_WIDE_SPLIT
   return 1;
 #else
-  if (a.taps != 9 || a.out_nchw || a.w_img_stride_f4 != 0 || a.Cout % 128 != 0) return 1;
+  // (1x1 convs of these levels on the same form measured neutral: 5.86 -> 5.54 ms of 1x1 time per step, given back by the reduction launches)
+  if (a.taps != 9) return 1;
+  if (a.out_nchw || a.w_img_stride_f4 != 0 || a.Cout % 128 != 0) return 1;
   const int hw = a.H * a.W;
   if (hw > 128 || !((a.H % 8 == 0 && a.W % 16 == 0) || (a.H % 4 == 0 && a.W % 8 == 0))) return 1;
   const long long rows = (long long)a.N * hw;
   if (rows < 1024) return 1;  // (sparse launches keep the narrow tiles: a batch-1 step would fill half a wide tile)
-  const int bm = (a.H % 8 == 0 && a.W % 16 == 0) ? 256 : 128;  // (4x8 maps: 128-pixel x 128-channel tiles on 4 waves, dispatch_s2_bn)
+  const int bm = (a.taps == 1 || (a.H % 8 == 0 && a.W % 16 == 0)) ? 256 : 128;  // (3x3 on 4x8 maps: 128-pixel x 128-channel tiles on 4 waves, dispatch_s2_bn)
   const long long tiles = ((rows + bm - 1) / bm) * (a.Cout / 128);
   if (tiles >= S2_MIN_WIDE_TILES) return 1;
   const int nch = (a.C0 + a.C1) / 32;

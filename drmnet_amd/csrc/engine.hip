@@ -160,6 +160,7 @@ int UNet::build(const drm_unet_desc& d) {
   te2_w = add_copy("time_embed.2.weight", {emb_dim, emb_dim});
   te2_b = add_copy("time_embed.2.bias", {emb_dim});
   stem_w = add_conv("input_blocks.0.0.weight", mc, d.in_channels, 3, mc, in_cp, false, &stem_s);
+  stem_param = (int)params.size() - 1;
   stem_b = add_copy("input_blocks.0.0.bias", {mc});
   input_blocks.emplace_back();
 
@@ -223,6 +224,7 @@ int UNet::build(const drm_unet_desc& d) {
   if (d.kind == 0) {
     DRM_REQUIRE(ch == mc, "UNetModel head expects model_channels inputs");
     oc_w = add_conv("out.2.weight", d.out_channels, mc, 3, out_cp, mc, false, &oc_s);
+    head_param = (int)params.size() - 1;
     oc_b = add_copy("out.2.bias", {d.out_channels}, out_cp);
   } else {
     oc_w = add_copy("out.3.weight", {d.out_channels, ch, 1, 1});
@@ -230,6 +232,16 @@ int UNet::build(const drm_unet_desc& d) {
   }
   scratch_off = wbuf_floats;
   wbuf_floats += 64;
+#ifndef DRM_NO_DIRECT_ENDS  // (A/B builds: tools/build_variant.sh)
+  if (stem_direct_applicable(d.in_channels, mc)) {
+    stem_direct_w = (long long)wbuf_floats;
+    wbuf_floats += (stem_weight_floats() + 63) & ~size_t(63);
+  }
+  if (false && d.kind == 0 && head_direct_applicable(ch, d.out_channels)) {  // (head_conv_kernel measures 0.36 ms against 0.31 ms for the generic path: not yet)
+    head_direct_w = (long long)wbuf_floats;
+    wbuf_floats += (head_weight_floats(ch) + 63) & ~size_t(63);
+  }
+#endif
   // fused embedding projection
   embcat_w = wbuf_floats;
   wbuf_floats += ((size_t)emb_total * emb_dim + 63) & ~size_t(63);
@@ -261,6 +273,8 @@ int UNet::load(const float* const* ptrs, int count, hipStream_t s, int set) {
       DRM_TRY(launch_pack_conv_weight(ptrs[i], wbuf + p.dst, p.cout, p.cin, p.taps, p.coutp, p.cinp, s));
     }
   }
+  if (stem_direct_w >= 0) DRM_TRY(launch_pack_stem_weight(ptrs[stem_param], wbuf + stem_direct_w, desc.model_channels, desc.in_channels, precision == PREC_FP32, s));
+  if (head_direct_w >= 0) DRM_TRY(launch_pack_head_weight(ptrs[head_param], wbuf + head_direct_w, desc.out_channels, final_ch, s));
   loaded[set] = true;
   loaded_precision[set] = precision;
   return DRM_OK;
@@ -558,16 +572,21 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
     }
   } pool_scope{ar};
 
-  Act xin = new_act(c, in_cp, H, W);
+  const bool stem_direct = stem_direct_w >= 0;
+  Act xin;
   const int amax_parts = pack_input_absmax_parts(H, W);
-  unsigned* amax = c.ar->alloc<unsigned>((size_t)N * amax_parts);  // max |input| per (image, pack block): every word is written by the pack kernel
+  unsigned* amax = nullptr;
+  if (!stem_direct) {
+    xin = new_act(c, in_cp, H, W);
+    amax = c.ar->alloc<unsigned>((size_t)N * amax_parts);  // max |input| per (image, pack block): every word is written by the pack kernel
+  }
   float* temb = c.ar->alloc<float>((size_t)N * mc);
   float* e1 = c.ar->alloc<float>((size_t)N * emb_dim);
   float* emb = c.ar->alloc<float>((size_t)N * emb_dim);
   float* emb_all = c.ar->alloc<float>((size_t)N * emb_total);
   DRM_TRY(arena_ok(c));
   if (!c.dry()) {
-    DRM_TRY(launch_pack_input(x, cond, rows, xin.p, N, H, W, Cx, Cc, in_cp, s, amax));
+    if (!stem_direct) DRM_TRY(launch_pack_input(x, cond, rows, xin.p, N, H, W, Cx, Cc, in_cp, s, amax));
     const float* te = t_emb;
     if (!te) {
       DRM_TRY(launch_timestep_embedding(t, tf, temb, N, mc, s));
@@ -585,12 +604,22 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   };
   std::vector<Act*> hs;
   Act* h = make(mc, H, W);
-  ConvArgs a;  // stem conv: raw network input
-  DRM_TRY(raw_input_guard(c, a, nullptr, 0, 0, nullptr, amax, in_cp, amax_parts));
-  if (!c.dry()) {
-    a.src0 = xin.p; a.C0 = in_cp; a.N = N; a.H = H; a.W = W;
-    a.w = Wb + stem_w; a.bias = Wb + stem_b; a.taps = 9; a.Cout = mc; a.out = h->p; a.cin_real = desc.in_channels;
-    DRM_TRY(run_conv(c, a, Wb, stem_s, h));
+  if (stem_direct) {
+    // stem conv on the NCHW boundary tensors (cat, row gather, exact fp32 products and the output's GroupNorm sums in one launch: stemhead.hip)
+    if (!c.dry()) {
+      if (!h->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(h->mom, 0, (size_t)N * mc * sizeof(double2), s));
+      DRM_TRY(launch_stem_conv(x, Cx, cond, Cc, rows, Wb + stem_direct_w, Wb + stem_b, h->p, h->mom, N, H, W, mc, precision == PREC_FP32, s));
+    }
+    h->mom_valid = true;
+    h->mom_sums = true;
+  } else {
+    ConvArgs a;  // stem conv: raw network input
+    DRM_TRY(raw_input_guard(c, a, nullptr, 0, 0, nullptr, amax, in_cp, amax_parts));
+    if (!c.dry()) {
+      a.src0 = xin.p; a.C0 = in_cp; a.N = N; a.H = H; a.W = W;
+      a.w = Wb + stem_w; a.bias = Wb + stem_b; a.taps = 9; a.Cout = mc; a.out = h->p; a.cin_real = desc.in_channels;
+      DRM_TRY(run_conv(c, a, Wb, stem_s, h));
+    }
   }
   hs.push_back(h);
 
@@ -644,7 +673,9 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   DRM_TRY(arena_ok(c));
   DRM_TRY(gn_params(c, *h, nullptr, Wb + on_w, Wb + on_b, sc, sh, nullptr, nullptr));
   if (!c.dry()) {
-    if (desc.kind == 0) {
+    if (desc.kind == 0 && head_direct_w >= 0) {
+      DRM_TRY(launch_head_conv(h->p, sc, sh, Wb + head_direct_w, Wb + oc_b, out, N, h->H, h->W, final_ch, desc.out_channels, s));
+    } else if (desc.kind == 0) {
       ConvArgs a;
       a.src0 = h->p; a.C0 = final_ch; a.N = N; a.H = h->H; a.W = h->W;
       a.gn_scale = sc; a.gn_shift = sh; a.silu = 1;
