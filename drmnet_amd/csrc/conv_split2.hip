@@ -152,7 +152,32 @@ __device__ __forceinline__ float silu2(float v) { return v * __builtin_amdgcn_rc
 __device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
   const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
   hi = (_Float16)c;
-  lo = (_Float16)(c - (float)hi);
+  lo = (_Float16)fmaf((float)hi, -1.0f, c);  // = c - hi exactly, one v_fma_mix_f32
+}
+// Two fp32 -> one register of two fp16 (round to nearest even: v_cvt_pk_f16_f32), and c - hi for the fp16 in the low / high half of such a
+// register in ONE instruction (v_fma_mix_f32 c * 1.0 + (-hi), the half read in place: exact).  The split of a staged value used to cost
+// v_cvt_f16_f32 + v_cvt_f32_f16 + v_sub_f32 per value on top of the packing; the staging VALU work is ~12 % of a 3x3 launch (measured by removing it).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2)); }
+template <int HALF>
+__device__ __forceinline__ float sub_packed_f16(float c, unsigned pk) {
+  float r;
+  if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(c), "v"(pk));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(c), "v"(pk));
+  return r;
+}
+// eight values -> hi (four registers of fp16 pairs) and the fp32 residuals c - hi; the values are clamped to [-lim_n, lim_p] first (both 0 on a
+// padding pixel: conv zero padding applies after norm + activation)
+__device__ __forceinline__ void split8(const float (&v)[8], float lim_n, float lim_p, float (&c8)[8], unsigned (&hi)[4], float (&l8)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c8[k] = __builtin_amdgcn_fmed3f(v[k], lim_n, lim_p);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hi[k] = cvt_pk_f16(c8[2 * k], c8[2 * k + 1]);
+    l8[2 * k] = sub_packed_f16<0>(c8[2 * k], hi[k]);
+    l8[2 * k + 1] = sub_packed_f16<1>(c8[2 * k + 1], hi[k]);
+  }
 }
 union F4H8b {
   float4 f4;
@@ -391,7 +416,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         const float s8[8] = {sc[0].x, sc[0].y, sc[0].z, sc[0].w, sc[1].x, sc[1].y, sc[1].z, sc[1].w};
         const float b8[8] = {sh[0].x, sh[0].y, sh[0].z, sh[0].w, sh[1].x, sh[1].y, sh[1].z, sh[1].w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = v[k] * s8[k] + b8[k];
+        for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], s8[k], b8[k]);  // (one v_fma_f32 per value; the unfused form compiled to packed mul + packed add, twice the issue time)
       }
       if (a.silu) {
 #pragma unroll
@@ -410,14 +435,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         // the +-65504 clamp of the other split modes was built and measured: two more v_med3 per value, 782 vs 792 steps/s on
         // one box (-1.3 %) for a range no activation of these networks reaches -- not adopted; the limit is stated in include/drmnet_hip.h
         // (DRM_PREC_F16MX) and tests/test_gpu_f16mx.py drives an input beyond it (finite, saturated).
-        F4H8b hi;
         float c8[8], l8[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          c8[k] = __builtin_amdgcn_fmed3f(ok ? v[k] : 0.f, -MX_A_LIM, MX_A_LIM);
-          hi.h8[k] = (_Float16)c8[k];
-          l8[k] = c8[k] - (float)hi.h8[k];
-        }
+        unsigned hi[4];
+        split8(v, ok ? -MX_A_LIM : 0.f, ok ? MX_A_LIM : 0.f, c8, hi, l8);
         s16x2 q[4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           y = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(y, c8[4 * k], c8[4 * k + 1], MX_AH_DIV, false);
           q[2 + k] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(y, c8[4 * k + 2], c8[4 * k + 3], MX_AH_DIV, true);
         }
-        areg[j][0] = f32x4{hi.f4.x, hi.f4.y, hi.f4.z, hi.f4.w};
+        areg[j][0] = f32x4{__builtin_bit_cast(float, hi[0]), __builtin_bit_cast(float, hi[1]), __builtin_bit_cast(float, hi[2]), __builtin_bit_cast(float, hi[3])};
         areg[j][1] = f32x4{__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]), __builtin_bit_cast(float, q[2]), __builtin_bit_cast(float, q[3])};
       } else if constexpr (TERMS == 4) {
         F4H8b hi;  // bf16 operands (round to nearest even: v_cvt_pk_bf16_f32); no range clamp needed, bf16 has fp32's exponent
@@ -436,16 +456,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         for (int k = 0; k < 8; ++k) hi.b8[k] = (__bf16)(ok ? v[k] : 0.f);
         areg[j][0] = f32x4{hi.f4.x, hi.f4.y, hi.f4.z, hi.f4.w};
       } else {
-        F4H8b hi, lo;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          _Float16 hh, ll;
-          split2(ok ? v[k] : 0.f, hh, ll);
-          hi.h8[k] = hh;
-          lo.h8[k] = ll;
-        }
-        areg[j][0] = f32x4{hi.f4.x, hi.f4.y, hi.f4.z, hi.f4.w};
-        areg[j][1] = f32x4{lo.f4.x, lo.f4.y, lo.f4.z, lo.f4.w};
+        float c8[8], l8[8];
+        unsigned hi[4];
+        split8(v, ok ? -65504.0f : 0.f, ok ? 65504.0f : 0.f, c8, hi, l8);
+        areg[j][0] = f32x4{__builtin_bit_cast(float, hi[0]), __builtin_bit_cast(float, hi[1]), __builtin_bit_cast(float, hi[2]), __builtin_bit_cast(float, hi[3])};
+        if constexpr (TERMS == 3)
+          areg[j][1] = f32x4{__builtin_bit_cast(float, cvt_pk_f16(l8[0], l8[1])), __builtin_bit_cast(float, cvt_pk_f16(l8[2], l8[3])),
+                             __builtin_bit_cast(float, cvt_pk_f16(l8[4], l8[5])), __builtin_bit_cast(float, cvt_pk_f16(l8[6], l8[7]))};
       }
     }
   };
@@ -855,6 +872,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
         ++step;
         constexpr bool a_younger = (g >= A_G) && (g - A_G <= R - 2);
         if (last_g) {
+#ifdef DRM_EXP_NOSTAGE  // timing experiment (wrong numbers): the chunk-end staging phase removed -- the bound of what hiding it can return
+          if (a_next) {
+            wait_vmcnt<C::G_PER * (C::NG - 1 - A_G)>();
+            tie_A();
+#if DRM_EXP_NOSTAGE >= 2
+            transform_A();
+            tie_A();  // (keeps the transform alive)
+#endif
+            wait_vmcnt<BASE>();
+            __builtin_amdgcn_s_barrier();
+          } else
+#endif
           if (a_next) {
             wait_vmcnt<C::G_PER * (C::NG - 1 - A_G)>();  // the request of group A_G; younger: the weight groups issued after it
             S2_STAMP(5);  // activation loads landed
