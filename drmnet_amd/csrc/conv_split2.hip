@@ -1030,7 +1030,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           // weight and (per image) input staging factors, all 2^-k (attention GEMMs: the "weights" are per image, and in_inv carries alpha)
           sv[g] = (a.w_inv_img ? a.w_inv_img[nimg[g]] : inv_scale) * (a.in_inv ? a.in_inv[nimg[g]] : 1.0f);
         }
-        if (a.res && first) {
+#ifdef DRM_S2_STAMP
+        const bool abl_noload = a.stamp_block & 0x200000;  // timing experiments (tools/epi_ablate.sh): no residual loads
+#else
+        constexpr bool abl_noload = false;
+#endif
+        if (a.res && first && !abl_noload) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) rv[e] = a.res[(pixb[e >> 2] + (e & 3)) * a.Cout + co];
         } else {
@@ -1044,6 +1049,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           const int g = e >> 2;
           v[e] = acc[i][c][e] * sv[g] + bias + ev[g] + rv[e];
           acc[i][c][e] = 0.f;  // ready for the next tile
+#ifdef DRM_S2_STAMP
+          if (a.stamp_block & 0x100000) continue;  // timing experiment: no statistics arithmetic
+#endif
           if (okg[g]) {
             if (e < 8) {
               s0 += v[e];
@@ -1072,6 +1080,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           const int cq = cur.co0 + (wn * NT + c) * 32 + (r & ~3);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
+#ifdef DRM_S2_STAMP
+            if (a.stamp_block & 0x400000) {  // timing experiment: no transposes, no stores
+              if (v[4 * g] == 12345.678f) out_s[0] = v[4 * g + 1] + v[4 * g + 2] + v[4 * g + 3];
+              continue;
+            }
+#endif
             quad_transpose(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], r);
 #ifdef DRM_S2_STAMP
             if (a.stamp_block & 0x10000) {
@@ -1089,7 +1103,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           }
         }
         S2_STAMP(22 + 4 * (i * NT + c));  // stores issued
-        if (st && first) {
+#ifdef DRM_S2_STAMP
+        const bool abl_noatom = a.stamp_block & 0x80000;  // timing experiment: no LDS statistics atomics
+#else
+        constexpr bool abl_noatom = false;
+#endif
+        if (st && first && !abl_noatom) {
           const int row0 = (wm * MT + i) * 32;
           if (PPI >= 32) {
             s0 += s1;
