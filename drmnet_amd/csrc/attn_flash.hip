@@ -409,7 +409,12 @@ __global__ __launch_bounds__(256) void pack_attn_v_perm_kernel(const float* __re
   }
 }
 
-bool attention_flash_applicable(int T, int C, int terms) { return (terms == 3 || terms == 1 || terms == 4) && C == 384 && T % FA_KT == 0 && T >= 1024; }
+// (T = 512 -- RefNet's 16x32 level at the metric shape, 128 workgroups at batch 32 -- measured 0.106 ms per core against 0.114 ms for the
+//  conv-pipeline form: the three packing launches and the half-empty chip eat the kernel's advantage; from T = 1024 it is 0.224 vs ~0.45 ms)
+#ifndef FA_MIN_T
+#define FA_MIN_T 1024
+#endif
+bool attention_flash_applicable(int T, int C, int terms) { return (terms == 3 || terms == 1 || terms == 4) && C == 384 && T % FA_KT == 0 && T >= FA_MIN_T; }
 
 size_t attention_flash_workspace_floats(int N, int T, int C) {
   const size_t Z = (size_t)(C > T ? C : T);
