@@ -156,6 +156,7 @@ def make_step(args, model, dev):
 
         gf = GFLOP["illnet"].get(key, 0) + GFLOP["refnet"].get(key, 0)
         step.state = Lr_k  # the tensor every step updates in place: main() checks it stays finite
+        step.counter = state  # {"i": steps done}: the reverse-step index and the Philox key of the next step
         return step, gf, "DRMNet reverse step = RefNet + z-MLP + IllNet + update (all rows active)"
     if args.workload in ("illnet", "refnet", "obsnet"):
         unet = {"illnet": lambda: model.illnet_model.diffusion_model, "refnet": lambda: model.refnet_model.diffusion_model,
@@ -223,6 +224,24 @@ def parity_check(model, dev, precision):
     except (OSError, KeyError) as e:  # fixtures not shipped with this copy
         res["error"] = str(e)
     return res
+
+
+def obsnet_parity(obs, dev) -> dict:
+    """The third shipped network against its reference output (tests/golden/full_obsnet_128x256.npz), in the mode `obs` runs in."""
+    import numpy as np
+    from drmnet_amd import synth
+
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "full_obsnet_128x256.npz"))
+        x = synth.synth_refmaps(1, 128, 256, synth.SEED_INPUT)
+        gen = torch.Generator().manual_seed(synth.SEED_INPUT + 1)
+        xk = x + 0.025 * torch.randn(x.shape, generator=gen)
+        xc = torch.cat([xk, x], dim=1).contiguous().to(dev)
+        out = obs.model.diffusion_model(xc, torch.from_numpy(g["t"]).to(dev))
+        ref = torch.from_numpy(g["out"]).double()
+        return {"obsnet 1x3x128x256 vs reference output": float(((out.cpu().double() - ref).norm() / ref.norm()).item())}
+    except (OSError, KeyError) as e:
+        return {"obsnet error": str(e)}
 
 
 def cpu_baseline(args):
@@ -316,51 +335,101 @@ def under_profiler() -> bool:
     return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
 
 
-def live_traffic(args, dominant: str, timeout_s: int = 300) -> dict:
-    """roofline.traffic measured IN this run (VERDICT r03 weak 10): two child runs of this same script under `rocprofv3 --pmc FETCH_SIZE` and
-    `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: MI355X_MICROARCH.md HBM section), three steps each, started as child processes
-    (never exec'd: this process holds the GPU); per launch of `dominant`: 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 reports half of wide streaming
-    reads).  Returns {} when rocprofv3 is not there, a child fails or its database cannot be read -- the committed profile is imported then."""
+CHILD_ENV_DROP = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "DRM_BENCH_DIST",
+                  "TORCHELASTIC_RUN_ID", "DRM_LIB_PATH_CHILD")
+
+
+def pmc_child(args, counters, timeout_s: int = 300):
+    """One child run of this script under `rocprofv3 --pmc <counters> --kernel-trace` (a fresh process in its own session: never an exec, this
+    process holds the GPU; the whole process group is killed on a timeout; rank / rendezvous variables are not inherited).  Returns
+    {kernel name: {"n": dispatches, "duration_ns": sum, counter: sum, ...}} or None."""
     import glob
     import shutil
+    import signal
     import sqlite3
     import subprocess
     import tempfile
 
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rp) or under_profiler():
-        return {}
-    per_launch = {}
+        return None
+    env = {k: v for k, v in os.environ.items() if k not in CHILD_ENV_DROP}
+    env["TMPDIR"] = "/tmp"
     try:
         with tempfile.TemporaryDirectory(prefix="drm_pmc_", dir="/tmp") as td:
-            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-                out = os.path.join(td, ctr)
-                cmd = [rp, "--pmc", ctr, "--kernel-trace", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--precision", args.precision,
-                       "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--steps", "2", "--warmup", "1",
-                       "--no-cpu-baseline", "--no-profile", "--no-parity-check", "--no-strict-fp32", "--no-secondary", "--no-live-traffic"]
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
-                dbs = sorted(glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True))
-                if r.returncode != 0 or not dbs:
-                    return {}
-                con = sqlite3.connect(dbs[-1])
-                cols = [c[1] for c in con.execute("pragma table_info(counters_collection)")]
-                kcol = "kernel_name" if "kernel_name" in cols else [c for c in cols if "kernel" in c and "name" in c][0]
-                total, disp = 0.0, set()
-                for name, d, v in con.execute(f"select {kcol}, dispatch_id, value from counters_collection where counter_name = ?", (ctr,)):
-                    if name.split("(")[0] == dominant:
-                        total += v
-                        disp.add(d)
-                con.close()
-                if not disp:
-                    return {}
-                per_launch[ctr] = (total / len(disp), len(disp))
+            cmd = [rp, "--pmc", *counters, "--kernel-trace", "-d", td, "--", sys.executable, os.path.abspath(__file__), "--precision", args.precision,
+                   "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-profile", "--no-parity-check", "--no-strict-fp32", "--no-secondary", "--no-live-traffic"]
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)  # rocprofv3 AND the python it started
+                except ProcessLookupError:
+                    pass
+                pr.wait()
+                return None
+            dbs = sorted(glob.glob(os.path.join(td, "**", "*_results.db"), recursive=True))
+            if rc != 0 or not dbs:
+                return None
+            con = sqlite3.connect(dbs[-1])
+            cols = [c[1] for c in con.execute("pragma table_info(counters_collection)")]
+            kcol = "kernel_name" if "kernel_name" in cols else [c for c in cols if "kernel" in c and "name" in c][0]
+            dcol = ", duration" if "duration" in cols else ", 0"
+            per, seen = {}, set()
+            for name, d, cname, v, dur in con.execute(f"select {kcol}, dispatch_id, counter_name, value{dcol} from counters_collection"):
+                k = per.setdefault(name.split("(")[0], {"n": 0, "duration_ns": 0.0})
+                k[cname] = k.get(cname, 0.0) + v
+                if d not in seen:
+                    seen.add(d)
+                    k["n"] += 1
+                    k["duration_ns"] += dur or 0.0
+            con.close()
+            return per
     except Exception:  # noqa: BLE001 -- any failure of the side measurement falls back to the committed profile
+        return None
+
+
+FAMILY_1X1 = ("conv_split2_kernel<1,",)
+FAMILY_ATTN = ("attn_", "softmax_rows", "pack_attn", "qk_small", "pv_small", "bgemm64s")
+
+
+def live_traffic(args, dominant: str, timeout_s: int = 300) -> dict:
+    """roofline.traffic measured IN this run (VERDICT r03 weak 10): two child runs of this same script under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: MI355X_MICROARCH.md HBM section), three steps each; per launch of `dominant`:
+    2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 reports half of wide streaming reads).  [r5] The same passes give the per-step traffic of the 1x1 conv
+    family and of the attention core's kernels (roofline_conv1x1 / roofline_attention), and a third child run (SQ_VALU_MFMA_BUSY_CYCLES,
+    GRBM_GUI_ACTIVE) the dominant variant's MFMA-busy fraction and the clock the chip held.  Returns {} when rocprofv3 is not there, a child fails or
+    its database cannot be read -- the committed profile is imported then."""
+    fe, wr = pmc_child(args, ["FETCH_SIZE"], timeout_s), None
+    if fe is not None:
+        wr = pmc_child(args, ["WRITE_SIZE"], timeout_s)
+    if fe is None or wr is None or dominant not in fe or dominant not in wr:
         return {}
-    fe, wr = per_launch["FETCH_SIZE"], per_launch["WRITE_SIZE"]
-    return {"traffic": int((2.0 * fe[0] + wr[0]) * 1024), "traffic_kernel": dominant,
-            "traffic_source": (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this command (separate passes, --kernel-trace only; "
-                               f"{fe[1]} / {wr[1]} launches of the dominant variant), 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; raw per launch: "
-                               f"FETCH_SIZE {fe[0]:.1f} KB, WRITE_SIZE {wr[0]:.1f} KB")}
+    f_dom, w_dom = fe[dominant], wr[dominant]
+    f_kb, w_kb = f_dom["FETCH_SIZE"] / f_dom["n"], w_dom["WRITE_SIZE"] / w_dom["n"]
+    out = {"traffic": int((2.0 * f_kb + w_kb) * 1024), "traffic_kernel": dominant,
+           "traffic_source": (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this command (separate passes, --kernel-trace only; "
+                              f"{f_dom['n']} / {w_dom['n']} launches of the dominant variant), 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; raw per launch: "
+                              f"FETCH_SIZE {f_kb:.1f} KB, WRITE_SIZE {w_kb:.1f} KB")}
+    steps_in_child = 3.0  # 1 warm-up + 2 timed steps, nothing else (every appended workload is switched off in the child)
+    for key, pats in (("family_traffic_conv1x1", FAMILY_1X1), ("family_traffic_attention", FAMILY_ATTN)):
+        f_sum = sum(v.get("FETCH_SIZE", 0.0) for k, v in fe.items() if any(p in k for p in pats))
+        w_sum = sum(v.get("WRITE_SIZE", 0.0) for k, v in wr.items() if any(p in k for p in pats))
+        n = sum(v["n"] for k, v in fe.items() if any(p in k for p in pats))
+        if n:
+            out[key] = {"bytes_per_step": int((2.0 * f_sum + w_sum) * 1024 / steps_in_child), "launches_per_step": round(n / steps_in_child, 1)}
+    sq = pmc_child(args, ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], timeout_s)
+    if sq is not None and dominant in sq and sq[dominant].get("GRBM_GUI_ACTIVE"):
+        d = sq[dominant]
+        gui = d["GRBM_GUI_ACTIVE"] / d["n"]  # summed over the 8 XCDs
+        out["mfma_busy"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["n"] / (1024.0 * gui / 8.0), 3)
+        if d["duration_ns"]:
+            out["clock_ghz"] = round(gui / 8.0 / (d["duration_ns"] / d["n"]), 3)
+        out["mfma_busy_source"] = (f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE child run of this command ({d['n']} launches of the dominant variant): "
+                                   "busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); clock = GRBM_GUI_ACTIVE / 8 / launch duration (MI355X_MICROARCH.md, DVFS give-back)")
+    return out
 
 
 def rank_aggregate(dt_local: float, units_local: float, dist=None, device=None):
@@ -423,6 +492,38 @@ def self_launch(args, command=None, have=None, poll_s=0.2) -> int:
         if live:
             time.sleep(poll_s)
     return rc
+
+
+def model_nets(model) -> dict:
+    if isinstance(model, tuple):
+        return {"illnet": model[0].illnet_model.diffusion_model, "refnet": model[0].refnet_model.diffusion_model, "obsnet": model[1].model.diffusion_model}
+    if hasattr(model, "illnet_model"):
+        return {"illnet": model.illnet_model.diffusion_model, "refnet": model.refnet_model.diffusion_model}
+    return {"obsnet": model.model.diffusion_model} if hasattr(model, "model") else {}
+
+
+def restore_modes(model, chosen: dict) -> None:
+    """Every network back to the mode the headline ran it in (auto mode may have chosen differently per network: ADVICE r4)."""
+    for k, net in model_nets(model).items():
+        if k in chosen and net.precision != chosen[k]:
+            net._set_mode(chosen[k])
+
+
+def timed_state_check(args, model, dev, initial, i0: int, final) -> dict:
+    """the state the TIMED loop produced, against the same steps from the same state in f16x3 (the three-product split mode every
+    test holds to the fp32 tolerances).  Same reverse-step indices, same Philox keys; rel-L2 of the final states must stay inside the 1e-4 contract."""
+    for net in model_nets(model).values():
+        net._set_mode("f16x3")
+    step, _, _ = make_step(args, model, dev)
+    step.state.copy_(initial)
+    step.counter["i"] = i0
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    a, b = final.double().flatten(1), step.state.double().flatten(1)
+    rows = ((a - b).norm(dim=1) / b.norm(dim=1).clamp_min(1e-300))
+    return {"timed_state_rel_l2": float(((a - b).norm() / b.norm()).item()), "worst_row": float(rows.max().item()), "steps": args.steps, "against": "f16x3",
+            "tolerance": 1e-4, "note": "the final state of the timed loop vs the same steps (indices, Philox keys) from the same initial state in f16x3"}
 
 
 def strict_fp32_pass(args, model, dev, L, _lib, precision="fp32"):
@@ -498,9 +599,12 @@ def secondary_pass(args, model, dev):
     # ---- ObsNet DDIM-50 chain, batch 256 @3x128x256 (BASELINE configs[2])
     acc = args.precision  # the accurate mode the headline ran in
     obs = build_models("obsnet", dev, getattr(args, "precision_requested", acc))
-    if obs.model.diffusion_model.calibrate_precision() is not None:  # --precision auto: ObsNet measures itself too
-        out["obsnet_precision_auto"] = obs.model.diffusion_model.auto_report
+    if getattr(args, "precision_requested", acc) == "auto":  # --precision auto: ObsNet measures itself too (network probe + DDIM chain probe)
+        obs.calibrate_precision()
+        out["obsnet_precision_auto"] = dict(obs.model.diffusion_model.auto_report or {}, chain=obs.auto_chain_report)
         acc = obs.model.diffusion_model.precision
+        obs._auto_chain = None  # (the explicit modes below are not to be second-guessed)
+    out["obsnet_parity"] = obsnet_parity(obs, dev)
     x = synth.synth_refmaps(256, 128, 256, synth.SEED_INPUT).to(dev)
     xT = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
     chains = {}
@@ -660,30 +764,46 @@ def main():
 
     L = _lib.lib()
     model = build_models(args.workload, dev, args.precision)
-    step, gflop, desc = make_step(args, model, dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # --precision auto: every network has measured itself against f16x3 on its first forward and settled on f16mx or f16x3
+    # --precision auto is resolved HERE, before any warm-up or timed step (with --warmup 0 the probes would otherwise run inside the timed
+    # region and the line would be labelled with the pre-calibration mode): every network measures f16mx against f16x3 on its loaded weights (probe
+    # batch: unet.py), then the model's chain probe (eight reverse / DDIM steps) has the last word
     requested_precision = args.precision
     auto_report = None
+    nets = model_nets(model)
     if args.precision == "auto":
-        nets = ({"illnet": model.illnet_model.diffusion_model, "refnet": model.refnet_model.diffusion_model} if hasattr(model, "illnet_model")
-                else {"obsnet": model.model.diffusion_model} if hasattr(model, "model") else {})
-        if isinstance(model, tuple):
-            nets = {"illnet": model[0].illnet_model.diffusion_model, "refnet": model[0].refnet_model.diffusion_model, "obsnet": model[1].model.diffusion_model}
+        for mdl in (model if isinstance(model, tuple) else (model,)):
+            mdl.calibrate_precision()
         auto_report = {k: v.auto_report for k, v in nets.items()}
+        for mdl, tag in zip(model if isinstance(model, tuple) else (model,), ("drmnet_chain", "obsnet_chain") if isinstance(model, tuple) else
+                            (("drmnet_chain",) if hasattr(model, "illnet_model") else ("obsnet_chain",))):
+            auto_report[tag] = mdl.auto_chain_report
         chosen = {k: v.precision for k, v in nets.items()}
         # the arithmetic the line is labelled with = that of the network carrying the FLOPs (IllNet / ObsNet)
         args.precision = chosen.get("illnet") or chosen.get("obsnet") or "f16x3"
         args.precision_requested = requested_precision
         auto_report["chosen"] = chosen
+        if dist is not None:  # the probes are seeded, so every rank must have come to the same choice
+            code = torch.tensor([sum((1 << i) for i, k in enumerate(sorted(chosen)) if chosen[k] == "f16mx")], dtype=torch.int64, device=dev)
+            lo, hi = code.clone(), code.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if int(lo.item()) != int(hi.item()):
+                print(f"bench.py: ranks disagree on the auto precision choice (codes {int(lo.item())} .. {int(hi.item())})", file=sys.stderr)
+                sys.exit(4)
+    chosen_modes = {k: v.precision for k, v in nets.items()}
+    step, gflop, desc = make_step(args, model, dev)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # the state the timed loop starts from (re-run in f16x3 afterwards: timed_state_check)
+    state0 = getattr(step, "state", None)
+    state0 = None if state0 is None or not hasattr(step, "counter") else (state0.clone(), int(step.counter["i"]))
     profile = not args.no_profile
     if profile:  # the timed region instruments the dominant kernel family only (HIP events around the fused 3x3 convs)
         L.drm_profile_reset()
@@ -699,6 +819,7 @@ def main():
     if state_finite is False:
         print("bench.py: the sampler state went non-finite inside the timed region; the measurement is invalid", file=sys.stderr)
         sys.exit(3)
+    state_final = None if state0 is None else state.clone()
     timed = None
     timed_variants = {}
     if profile:
@@ -785,12 +906,18 @@ def main():
                 if tr.get("traffic") is not None and tr.get("traffic_kernel") == dom:
                     roofline["dominant_variant"]["traffic"] = tr["traffic"]
                     roofline["dominant_variant"]["traffic_ratio"] = round(tr["traffic"] / (dv["bytes"] / dv["launches"]), 3)
+            for k_ in ("mfma_busy", "clock_ghz", "mfma_busy_source"):
+                if k_ in tr:
+                    roofline[k_] = tr[k_]
+            family_traffic = {k_: tr[k_] for k_ in ("family_traffic_conv1x1", "family_traffic_attention") if k_ in tr}
             roofline["traffic"] = tr.get("traffic")
             roofline["traffic_is_for"] = "dominant_variant (see that object for the matching algorithmic bytes and the ratio)" if tr.get("traffic") is not None else None
             for k_ in ("traffic_source", "traffic_note", "traffic_committed_profile"):
                 if k_ in tr:
                     roofline[k_] = tr[k_]
         # the two other matrix families of the step (second, untimed pass: every family instrumented)
+        if n[0] <= 0:
+            family_traffic = {}
         for key_, k_idx, bound in (("roofline_conv1x1", 1, "hbm"), ("roofline_attention", 2, "mfma")):
             if n[k_idx] > 0 and ms[k_idx] > 0:
                 tf_ = fl[k_idx] / (ms[k_idx] * 1e-3) / 1e12
@@ -803,6 +930,11 @@ def main():
                                 "unit": "TFLOP/s", "frac": round(tf_ / mpeak, 4), "algorithmic_GBps": round(gbs, 1)})
                 extra[key_].update({"launches": int(n[k_idx]), "ms_per_step": round(ms[k_idx] / args.steps, 3), "traffic": None,
                                     "measured_in": "second, untimed pass of the same steps with every family instrumented"})
+                ft = family_traffic.get("family_traffic_conv1x1" if k_idx == 1 else "family_traffic_attention")
+                if ft:  # PMC bytes of the family's kernels per step, from the same child runs as roofline.traffic (2 x FETCH_SIZE + WRITE_SIZE)
+                    alg = by[k_idx] / args.steps
+                    extra[key_].update({"traffic": ft["bytes_per_step"], "traffic_unit": "HBM bytes per step (all launches of the family)", "algorithmic_bytes_per_step": round(alg, 1),
+                                        "traffic_ratio": round(ft["bytes_per_step"] / alg, 3) if alg > 0 else None, "traffic_launches_per_step": ft["launches_per_step"]})
 
     chain_all = None
     if (world > 1 or dist is not None) and args.workload == "drmnet_step" and args.precision in ("f16x3", "f16mx") and not args.no_secondary:
@@ -819,6 +951,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
+            "scaling_measured": bool(world > 1),  # (a single-GPU line carries no multi-GPU figure, measured or projected)
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "f16x3": "f32-accurate split: f16 hi/lo x3 MFMA, fp32 acc", "f16": "f16 operands, fp32 acc (reduced precision)",
                       "bf16": "bf16 operands, fp32 acc (reduced precision)",
@@ -843,6 +976,17 @@ def main():
             "kernel_breakdown_note": "conv3x3 row and the roofline object: HIP events inside the timed region; other rows: a second, untimed pass of the same steps with every kernel family instrumented",
         }
         out["state_finite"] = state_finite
+        if state0 is not None and world == 1 and args.workload == "drmnet_step" and args.precision == "f16mx" and not args.no_parity_check:
+            try:
+                out["timed_state_check"] = timed_state_check(args, model, dev, state0[0], state0[1], state_final)
+            except Exception as e:  # noqa: BLE001
+                out["timed_state_check"] = {"error": f"{type(e).__name__}: {e}"}
+            restore_modes(model, chosen_modes)
+            if out["timed_state_check"].get("timed_state_rel_l2", 0.0) >= 1e-4:
+                print(f"bench.py: the timed state differs from its f16x3 re-run by {out['timed_state_check']['timed_state_rel_l2']:.2e} (contract 1e-4): "
+                      "the headline arithmetic does not hold on this state", file=sys.stderr)
+                print(json.dumps(out), flush=True)
+                sys.exit(3)
         if chain_all is not None:
             out["full_chain_all_gpus"] = chain_all
         if args.workload == "drmnet_step" and not args.no_parity_check:
@@ -857,10 +1001,19 @@ def main():
                 out["strict_fp32"] = strict_fp32_pass(args, model, dev, L, _lib)
             except Exception as e:  # noqa: BLE001
                 out["strict_fp32"] = {"error": f"{type(e).__name__}: {e}"}
+            if requested_precision == "auto":
+                model.set_precision("auto")  # (back to auto mode: the stored reports put every network on its own choice again, nothing is re-measured)
+                model.calibrate_precision()
+            restore_modes(model, chosen_modes)
         if world == 1 and args.workload == "drmnet_step" and args.precision in ("f16x3", "f16mx") and not args.no_secondary and (args.batch, args.height, args.width) == (32, 128, 256):
             try:  # (the headline line must survive a failure of an appended workload)
-                model.set_precision(args.precision)
+                restore_modes(model, chosen_modes)
                 out["secondary"] = secondary_pass(args, model, dev)
+                if "parity_check" in out and "obsnet_parity" in out["secondary"]:  # the third network, in the mode its chains ran in
+                    out["parity_check"]["cases"].update(out["secondary"].pop("obsnet_parity"))
+                    vals = [v for v in out["parity_check"]["cases"].values() if isinstance(v, float)]
+                    out["parity_check"]["max_rel_l2"] = max(vals)
+                    out["parity_check"]["within_tolerance"] = bool(max(vals) < out["parity_check"]["tolerance_rel_l2"])
             except Exception as e:  # noqa: BLE001
                 out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
                 torch.cuda.empty_cache()

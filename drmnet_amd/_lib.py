@@ -25,7 +25,7 @@ SYMBOLS = [
     "drm_unet_workspace_bytes", "drm_unet_forward",
     "drm_linear_forward", "drm_timestep_embedding", "drm_op_norm_act_conv", "drm_op_resblock", "drm_op_attention_block",
     "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_step", "drm_drmnet_sample",
-    "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddpm_sample", "drm_randn",
+    "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddim_sample_logged", "drm_ddpm_sample", "drm_randn",
     "drm_profile_enable", "drm_profile_reset", "drm_profile_collect", "drm_unet_set_precision", "drm_set_op_precision",
     "drm_refmap_workspace_bytes", "drm_refmap_mask_make", "drm_erode_mask",
     "drm_unet_load_params_set", "drm_unet_use_set", "drm_set_graph_replay", "drm_graph_launches",
@@ -90,6 +90,8 @@ def lib() -> C.CDLL:
     L.drm_sampler_workspace_bytes.argtypes = [vp, i32, i32, i32]
     L.drm_sampler_workspace_bytes.restype = C.c_size_t
     L.drm_ddim_sample.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_ddim_sample_logged.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, fp, fp, i32, C.POINTER(C.c_int32),
+                                         i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_ddpm_sample.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_randn.argtypes = [fp, C.c_size_t, C.c_uint64, C.c_uint64, vp]
     u8p = vp

@@ -1,4 +1,5 @@
 // extern "C" surface of libdrmnet_hip.so (declared in include/drmnet_hip.h).
+#include <atomic>
 #include <cstring>
 #include <memory>
 
@@ -71,14 +72,17 @@ int with_scratch(hipStream_t s, Body&& body) {
   return DRM_OK;
 }
 
-int g_op_precision = PREC_FP32;  // arithmetic used by the drm_op_* entry points (drm_set_op_precision)
+// Arithmetic of the drm_op_* entry points (drm_set_op_precision).  The one piece of process-wide state behind the C ABI: an atomic word that every
+// drm_op_* call reads ONCE at entry (a call runs in one mode from its weight packing to its last launch); a concurrent drm_set_op_precision takes
+// effect for calls that start after it.  The network / sampler handles carry their own mode (drm_unet_set_precision).
+std::atomic<int> g_op_precision{PREC_FP32};
 
-// packs one conv weight for the current op precision; `slot` = 64-float scale slot (2^k, 2^-k), `scratch` = 1 uint
-int pack_for_ops(const float* w, float* dst, float* slot, float* scratch, int cout, int cin, int taps, int coutp, int cinp, hipStream_t s,
+// packs one conv weight for the op precision `prec`; `slot` = 64-float scale slot (2^k, 2^-k), `scratch` = 1 uint
+int pack_for_ops(int prec, const float* w, float* dst, float* slot, float* scratch, int cout, int cin, int taps, int coutp, int cinp, hipStream_t s,
                  bool mx_site = false) {
-  if (g_op_precision != PREC_FP32 && cinp % 32 == 0)
+  if (prec != PREC_FP32 && cinp % 32 == 0)
     return launch_pack_conv_weight_split(w, dst, slot, reinterpret_cast<unsigned*>(scratch), cout, cin, taps, coutp, cinp, s,
-                                         g_op_precision == PREC_F16MX && mx_site, g_op_precision == PREC_BF16);
+                                         prec == PREC_F16MX && mx_site, prec == PREC_BF16);
   return launch_pack_conv_weight(w, dst, cout, cin, taps, coutp, cinp, s);
 }
 
@@ -191,7 +195,8 @@ int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, 
     DRM_REQUIRE((!residual && !emb) || Cout == coutp, "residual/emb need Cout % 32 == 0");
     const size_t hw = (size_t)H * W;
     return with_scratch(s, [&](Arena& ar) -> int {
-      Ctx c{&ar, s, N, g_op_precision};
+      const int op_prec = g_op_precision.load(std::memory_order_relaxed);  // (read once: the whole call runs in this mode)
+      Ctx c{&ar, s, N, op_prec};
       Act xa = new_act(c, cinp, H, W);
       float* wb = ar.alloc<float>(64);  // base for offsets: [0..63] = scale slot, then scratch
       float* scratch = ar.alloc<float>(64);
@@ -210,7 +215,7 @@ int drm_op_norm_act_conv(const float* x, const float* gamma, const float* beta, 
         return DRM_OK;
       }
       DRM_TRY(launch_pack_input(x, nullptr, nullptr, xa.p, N, H, W, Cin, 0, cinp, s));
-      DRM_TRY(pack_for_ops(w, wp, wb, scratch, Cout, Cin, taps, coutp, cinp, s));
+      DRM_TRY(pack_for_ops(op_prec, w, wp, wb, scratch, Cout, Cin, taps, coutp, cinp, s));
       if (b) DRM_HIP_CHECK(hipMemcpyAsync(bp, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
       if (!gamma) {
         xa.mom_valid = false;
@@ -246,7 +251,8 @@ int drm_op_resblock(const float* x0, int C0, int up0, const float* x1, int C1, c
     DRM_REQUIRE(cin % 32 == 0 && Cout % 32 == 0 && C0 % 32 == 0, "channels % 32");
     DRM_REQUIRE(emb_dim <= 512, "emb_dim <= 512");
     return with_scratch(s, [&](Arena& ar) -> int {
-      Ctx c{&ar, s, N, g_op_precision};
+      const int op_prec = g_op_precision.load(std::memory_order_relaxed);  // (read once: the whole call runs in this mode)
+      Ctx c{&ar, s, N, op_prec};
       // packed weights laid out like UNet::add_res
       ResLayer r;
       r.cin = cin; r.cout = Cout; r.has_skip = has_skip; r.emb_off = 0;
@@ -272,12 +278,12 @@ int drm_op_resblock(const float* x0, int C0, int up0, const float* x1, int C1, c
           return DRM_OK;
         };
         DRM_TRY(cp(n1w, params[0], cin)); DRM_TRY(cp(n1b, params[1], cin));
-        DRM_TRY(pack_for_ops(params[2], c1w, s1, scratch, Cout, cin, 9, Cout, cin, s, true)); DRM_TRY(cp(c1b, params[3], Cout));
+        DRM_TRY(pack_for_ops(op_prec, params[2], c1w, s1, scratch, Cout, cin, 9, Cout, cin, s, true)); DRM_TRY(cp(c1b, params[3], Cout));
         DRM_TRY(launch_linear(emb, params[4], params[5], e_out, N, emb_dim, Cout, 1, 0, s));
         DRM_TRY(cp(n2w, params[6], Cout)); DRM_TRY(cp(n2b, params[7], Cout));
-        DRM_TRY(pack_for_ops(params[8], c2w, s2, scratch, Cout, Cout, 9, Cout, Cout, s, true)); DRM_TRY(cp(c2b, params[9], Cout));
+        DRM_TRY(pack_for_ops(op_prec, params[8], c2w, s2, scratch, Cout, Cout, 9, Cout, Cout, s, true)); DRM_TRY(cp(c2b, params[9], Cout));
         if (has_skip) {
-          DRM_TRY(pack_for_ops(params[10], skw, s3, scratch, Cout, cin, 1, Cout, cin, s)); DRM_TRY(cp(skb, params[11], Cout));
+          DRM_TRY(pack_for_ops(op_prec, params[10], skw, s3, scratch, Cout, cin, 1, Cout, cin, s)); DRM_TRY(cp(skb, params[11], Cout));
         }
         DRM_TRY(launch_nchw_to_nhwc(x0, a0.p, N, H >> up0, W >> up0, C0, s));
         if (C1 > 0) DRM_TRY(launch_nchw_to_nhwc(x1, a1.p, N, H, W, C1, s));
@@ -294,7 +300,8 @@ int drm_op_attention_block(const float* x, const float* const* params, float* ou
     hipStream_t s = static_cast<hipStream_t>(stream);
     DRM_REQUIRE(C % 32 == 0, "channels % 32");
     return with_scratch(s, [&](Arena& ar) -> int {
-      Ctx c{&ar, s, N, g_op_precision};
+      const int op_prec = g_op_precision.load(std::memory_order_relaxed);  // (read once: the whole call runs in this mode)
+      Ctx c{&ar, s, N, op_prec};
       AttnLayer l;
       l.ch = C;
       float* wb = ar.alloc<float>(1);
@@ -309,9 +316,9 @@ int drm_op_attention_block(const float* x, const float* const* params, float* ou
         l.n_w = off(nw); l.n_b = off(nb); l.qkv_w = off(qw); l.qkv_b = off(qb); l.proj_w = off(pw); l.proj_b = off(pb); l.qkv_s = off(s1); l.proj_s = off(s2);
         DRM_HIP_CHECK(hipMemcpyAsync(nw, params[0], C * sizeof(float), hipMemcpyDeviceToDevice, s));
         DRM_HIP_CHECK(hipMemcpyAsync(nb, params[1], C * sizeof(float), hipMemcpyDeviceToDevice, s));
-        DRM_TRY(pack_for_ops(params[2], qw, s1, scratch, 3 * C, C, 1, 3 * C, C, s));
+        DRM_TRY(pack_for_ops(op_prec, params[2], qw, s1, scratch, 3 * C, C, 1, 3 * C, C, s));
         DRM_HIP_CHECK(hipMemcpyAsync(qb, params[3], 3 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-        DRM_TRY(pack_for_ops(params[4], pw, s2, scratch, C, C, 1, C, C, s));
+        DRM_TRY(pack_for_ops(op_prec, params[4], pw, s2, scratch, C, C, 1, C, C, s));
         DRM_HIP_CHECK(hipMemcpyAsync(pb, params[5], C * sizeof(float), hipMemcpyDeviceToDevice, s));
         DRM_TRY(launch_nchw_to_nhwc(x, a.p, N, H, W, C, s));
       }
@@ -387,6 +394,22 @@ int drm_ddim_sample(drm_unet* net, float* x, const float* cond, const int64_t* t
   });
 }
 
+int drm_ddim_sample_logged(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
+                           const float* noise, uint64_t seed, int log_every_t, float* log_x, float* log_pred_x0, int log_slots, int32_t* n_logged, int N,
+                           int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && x && cond, "null argument");
+    DRM_REQUIRE(log_every_t > 0 && log_x && log_pred_x0 && log_slots > 0, "ddim intermediates: log_every_t, both log buffers and their slot count");
+    Arena ar;
+    DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
+    int logged = 0;
+    const int rc = ddim_sample(&net->net, x, cond, timesteps, coef, S, num_steps, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream), log_every_t, log_x,
+                               log_pred_x0, log_slots, &logged);
+    if (n_logged) *n_logged = logged;
+    return rc;
+  });
+}
+
 int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
                     const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
   return guarded([&]() -> int {
@@ -409,7 +432,7 @@ int drm_set_op_precision(int precision) {
   return guarded([&]() -> int {
     DRM_REQUIRE(precision_valid(precision),
                 "precision must be 0 (fp32 MFMA), 1 (split fp16 x3), 2 (plain fp16 operands), 3 (split fp16 with fp8 cross terms) or 4 (plain bf16 operands)");
-    g_op_precision = precision;
+    g_op_precision.store(precision, std::memory_order_relaxed);
     return DRM_OK;
   });
 }

@@ -18,7 +18,7 @@
 //     un-normalised operand of the split modes) into a ring of four 32-KiB slots, two steps ahead, retired by counted s_waitcnt vmcnt(N) + raw
 //     s_barrier (one per step; every wave issues the same number of DMA instructions per step, so the counts are compile-time constants);
 //   * arithmetic: the three-product fp16 split of every other matrix kernel here (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32
-//     accumulate) -- q, k, v AND the probabilities (scaled by 2^12 so that their lo halves stay normal) are split; TERMS = 1 (DRM_PREC_F16)
+//     accumulate) -- q, k, v AND the probabilities (staged as p * FA_PSCALE = p * 2^8 <= 2^14 with the lazy-rescale head-room 2^FA_TAU = 2^6; their fp16 lo halves are normal numbers for p >~ 2^-11 and go subnormal, then to zero, below -- a relative 2^-11 of a probability that is itself below 2^-11 of the row sum) are split; TERMS = 1 (DRM_PREC_F16)
 //     keeps the hi product only.  exp through v_exp_f32 on (s - m) log2(e).
 // Work: per 128-key tile and workgroup 2 x 1152 MFMAs (q k^T and P v at C = 384); k, v and the workgroup's q are re-read from L2 / the
 // Infinity Cache per key tile (the q / k / v images of a batch-32 pass are 300 MB).
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
   }
   fa_wait_vmcnt<0>();  // drain the wrapped prefetches before the workgroup's LDS can be re-assigned
 
-  // ---- epilogue: O^T / (l 2^12 2^kv): this lane's query, channels c * 32 + 8 g4 + 4 h + {0..3} per register group
+  // ---- epilogue: O^T / (l FA_PSCALE 2^kv) (FA_PSCALE = 2^8, the staging factor of the probabilities): this lane's query, channels c * 32 + 8 g4 + 4 h + {0..3} per register group
   const float l = l_run + __shfl_xor(l_run, 32);
   const float fo = v_inv[n] / (FA_PSCALE * l);
   float* op = out + ((size_t)n * T + q0 + wave * 32 + r) * C;

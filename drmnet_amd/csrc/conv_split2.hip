@@ -230,8 +230,17 @@ __device__ __forceinline__ void tie_regs(f32x4& x0, f32x4& x1) { asm volatile(""
 // XCDs (plain accesses without the fences: 358 M stale values across XCDs), 9 / 15 us per launch against 33 / 57 us with the fences.
 // (s_nop 1: a store of more than 8 bytes reads its data registers after issue -- the wait states the compiler inserts before it overwrites them
 //  are invisible to it inside asm; without them the next quad transpose corrupted the slab)
+// -DDRM_SK_FENCED=1: the conservative form of the same hand-off, kept compilable for A/Bs and as the switch to throw should a stale slab
+// ever show -- plain slab stores / loads around an agent-scope release fence (one lane, before the ticket) and acquire fences (every wave of the
+// finishing workgroup, after it): the LLVM memory model's documented release / acquire pair instead of per-access sc1 coherence.  19 vs 7 us per
+// hand-off at the 64x64 level of the batch-1 step (profiles/r04_sc1_handoff_probe.txt); tools/skab.sh compares the two builds.
+#ifdef DRM_SK_FENCED
+__device__ __forceinline__ void gstore16_agent(void* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void gload16_agent(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(d) : "v"(p) : "memory"); }
+#else
 __device__ __forceinline__ void gstore16_agent(void* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void gload16_agent(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(d) : "v"(p) : "memory"); }
+#endif
 __device__ __forceinline__ void tie_reg(f32x4& x) { asm volatile("" : "+v"(x)::"memory"); }
 
 // 4 x 4 transpose across the four lanes of a quad: in, lane q holds x_k = M[q][k]; out, lane q holds x_k = M[k][q].
@@ -1140,11 +1149,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           S2_STAMP(71);  // ... and complete at agent scope
           __builtin_amdgcn_s_barrier();
-          if (tid == 0)
+          if (tid == 0) {
+#ifdef DRM_SK_FENCED
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the workgroup's slab stores are complete -- vmcnt(0) + barrier above -- and now written back)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (cdna_hip_programming.md G16 pitfall 12: the fence's own wait may be dropped)
+#endif
             s_last_tile = __hip_atomic_fetch_add(a.tile_ticket + (x_start + k_tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ks - 1;
+          }
           __syncthreads();
           S2_STAMP(72);  // ticket drawn
           if (s_last_tile) {
+#ifdef DRM_SK_FENCED
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (every wave that loads slab bytes: its CU's L1 lines of them are invalidated)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             S2_STAMP(73);
             const int col = wn * 32 + r, co = cur.co0 + col;
             const int cq = cur.co0 + wn * 32 + (r & ~3);

@@ -33,8 +33,10 @@ class DrmnetSampler {
 size_t sampler_workspace_bytes(UNet* net, int N, int H, int W);
 void set_graph_replay(bool on);   // DDIM / DDPM chains: replay one captured hipGraph of a step (default off)
 long long graph_launches();       // hipGraphLaunch calls made so far (tests / bench read it)
+// log_every_t > 0 with log_x / log_pred ([log_slots][N,3,H,W] each): the reference's intermediates (ddim.py:198-200), *n_logged = slots written
 int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
-                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s);
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s, int log_every_t = 0, float* log_x = nullptr, float* log_pred = nullptr,
+                int log_slots = 0, int* n_logged = nullptr);
 int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip, const float* noise,
                 uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s);
 

@@ -147,7 +147,7 @@ __global__ void drmnet_record_kernel(const int32_t* __restrict__ rows, const int
 // DDIM / DDPM loops keep every per-step scalar in a DEVICE table (row j: timestep, five coefficients) indexed by a device
 // counter, so the launches of a step do not depend on j and one captured hipGraph of a step can be replayed for the whole chain
 // (BASELINE configs[2]: "hipGraph-captured step").  Table row layout: STEP_ROW floats.
-constexpr int STEP_ROW = 8;  // [0] timestep, [1..5] coefficients, [6] flag (DDPM: t > 0), [7] unused
+constexpr int STEP_ROW = 8;  // [0] timestep, [1..5] coefficients, [6] flag (DDPM: t > 0), [7] DDIM: 1 + slot of the intermediates log this step writes (0 = none)
 constexpr int MAX_TABLE_STEPS = 4096;  // sampler_workspace_bytes budgets the table for this many steps; the chain entry points check it
 
 __global__ void step_begin_kernel(const float* __restrict__ tab, const int* __restrict__ counter, float* __restrict__ tf, int N) {
@@ -157,8 +157,10 @@ __global__ void step_begin_kernel(const float* __restrict__ tab, const int* __re
 __global__ void step_advance_kernel(int* counter) { *counter += 1; }
 
 // pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);  x = sqrt(a_prev) pred_x0 + sqrt(1-a_prev-s^2) e + s * noise   (ddim.py:249-258)
+// log_x / log_pred (optional): the reference's `intermediates` (ddim.py:171-204): slots of n floats, written by the steps the table marks
 __global__ void ddim_update_kernel(float* __restrict__ x, const float* __restrict__ e, const float* __restrict__ noise, size_t n,
-                                   const float* __restrict__ tab, const int* __restrict__ counter, uint64_t seed) {
+                                   const float* __restrict__ tab, const int* __restrict__ counter, uint64_t seed, float* __restrict__ log_x,
+                                   float* __restrict__ log_pred) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int j = *counter;
@@ -168,7 +170,13 @@ __global__ void ddim_update_kernel(float* __restrict__ x, const float* __restric
   const float pred = (xv - s1m * ev) / sa;
   float nz = 0.f;
   if (sig != 0.f) nz = noise ? noise[(size_t)j * n + i] : philox_normal1(seed, (uint64_t)(j + 1) * n + i);
-  x[i] = sap * pred + sdir * ev + sig * nz;
+  const float xn = sap * pred + sdir * ev + sig * nz;
+  x[i] = xn;
+  const int slot = (int)c[6];  // (row element 7)
+  if (log_x && slot > 0) {
+    log_x[(size_t)(slot - 1) * n + i] = xn;
+    log_pred[(size_t)(slot - 1) * n + i] = pred;
+  }
 }
 
 // x_recon = c0 x - c1 e; mean = c2 x_recon + c3 x; x = mean + [t>0] c4 noise   (ddpm.py:233-246,1156-1167)
@@ -462,7 +470,8 @@ static int upload_step_table(const std::vector<float>& rows, float* tab, int* co
 }
 
 int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
-                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller) {
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller, int log_every_t, float* log_x, float* log_pred, int log_slots,
+                int* n_logged) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddim needs a UNetModel");
   DRM_REQUIRE(S >= 1 && timesteps && coef, "ddim schedule");
   DRM_REQUIRE(S <= MAX_TABLE_STEPS, "ddim: at most " + std::to_string(MAX_TABLE_STEPS) + " steps (the workspace budgets the step table for that many)");
@@ -477,11 +486,19 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
   int* counter = ar.alloc<int>(1);
   if (ar.failed) { set_error("ddim: workspace too small"); return DRM_ERR_WORKSPACE; }
   std::vector<float> rows((size_t)steps * STEP_ROW, 0.f);
+  int logged = 0;
+  DRM_REQUIRE(!log_x || log_pred, "ddim: the intermediates log needs both buffers");
   for (int j = 0; j < steps; ++j) {
     const int index = S - 1 - j;
     rows[(size_t)j * STEP_ROW] = (float)timesteps[index];
     for (int k = 0; k < 5; ++k) rows[(size_t)j * STEP_ROW + 1 + k] = coef[5 * index + k];
+    // the reference appends (img, pred_x0) after the step of `index` when index % log_every_t == 0 or at the first step (ddim.py:198-200)
+    if (log_x && log_every_t > 0 && (index % log_every_t == 0 || index == S - 1)) {
+      DRM_REQUIRE(logged < log_slots, "ddim: the intermediates log has too few slots");
+      rows[(size_t)j * STEP_ROW + 7] = (float)(++logged);
+    }
   }
+  if (n_logged) *n_logged = logged;
   DRM_TRY(upload_step_table(rows, tab, counter, s));
   const size_t mark = ar.mark();
   return run_steps(steps, s, [&]() -> int {
@@ -489,7 +506,7 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
     DRM_HIP_CHECK(hipGetLastError());
     ar.release(mark);
     DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
-    hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, e, noise, n, tab, counter, seed);
+    hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, e, noise, n, tab, counter, seed, log_x, log_pred);
     DRM_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);
     DRM_HIP_CHECK(hipGetLastError());

@@ -91,7 +91,9 @@ class DDIMSampler(object):
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, log_every_t=100, verbose=True, noise=None, seed=None, num_steps=None, **unused):
-        """ddim.py:128-204 -> (final x, {"x_inter": [x_T, x], "pred_x0": [x_T]})."""
+        """ddim.py:128-204 -> (final x, intermediates).  ``intermediates`` is the reference's record (ddim.py:171-204): "x_inter" and "pred_x0" start
+        with x_T and receive (img, pred_x0) after the step of ``index`` whenever index % log_every_t == 0 or at the first step -- written by the
+        update kernel of the steps the device table marks (csrc/samplers.hip), so the chain stays one device loop."""
         from . import ops
 
         dev = self.model.betas.device
@@ -104,14 +106,32 @@ class DDIMSampler(object):
         noise = None if noise is None else _lib.require_gpu_tensor(noise, "noise")
         unet = self.model.model.diffusion_model
         h = unet.engine_handle()
+        if getattr(self.model, "_auto_chain", None) is not None:  # auto mode: the model's chain probe may move the network to f16x3 for these weights
+            self.model._auto_chain_probe()
+            h = unet.engine_handle()
         L = _lib.lib()
         n, _, hh, ww = shape
         ws = self._ws.get(int(L.drm_sampler_workspace_bytes(h, n, hh, ww)), dev)
         ts = np.ascontiguousarray(np.asarray(self.ddim_timesteps, dtype=np.int64))
         coef = np.ascontiguousarray(self.ddim_coef)
         S = len(ts)
+        steps = S if not num_steps else min(int(num_steps), S)
+        log_every_t = int(log_every_t) if log_every_t else 0
+        slots = sum(1 for j in range(steps) if log_every_t > 0 and ((S - 1 - j) % log_every_t == 0 or j == 0))
+        inter = {"x_inter": [x_start], "pred_x0": [x_start]}
         with torch.cuda.device(dev):
-            _lib.check(L.drm_ddim_sample(h, img.data_ptr(), c.data_ptr(), ts.ctypes.data_as(C.POINTER(C.c_int64)),
-                                         coef.ctypes.data_as(C.POINTER(C.c_float)), S, int(num_steps or 0), _lib.ptr(noise), seed, n, hh, ww,
-                                         ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
-        return img, {"x_inter": [x_start, img], "pred_x0": [x_start]}
+            if slots == 0:
+                _lib.check(L.drm_ddim_sample(h, img.data_ptr(), c.data_ptr(), ts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             coef.ctypes.data_as(C.POINTER(C.c_float)), S, int(num_steps or 0), _lib.ptr(noise), seed, n, hh, ww,
+                                             ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+            else:
+                log_x = torch.empty((slots,) + tuple(img.shape), dtype=torch.float32, device=dev)
+                log_p = torch.empty_like(log_x)
+                n_logged = C.c_int32(0)
+                _lib.check(L.drm_ddim_sample_logged(h, img.data_ptr(), c.data_ptr(), ts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                    coef.ctypes.data_as(C.POINTER(C.c_float)), S, int(num_steps or 0), _lib.ptr(noise), seed, log_every_t,
+                                                    log_x.data_ptr(), log_p.data_ptr(), slots, C.byref(n_logged), n, hh, ww, ws.data_ptr(), ws.numel(),
+                                                    _lib.stream_ptr(dev)))
+                inter["x_inter"] += [log_x[k] for k in range(n_logged.value)]
+                inter["pred_x0"] += [log_p[k] for k in range(n_logged.value)]
+        return img, inter

@@ -202,10 +202,89 @@ class DRMNet(nn.Module):
         weights agrees with f16x3 to 5e-5, else f16x3: unet.set_precision_auto), "f16" / "bf16" (reduced precision)."""
         self.illnet_model.diffusion_model.set_precision(precision)
         self.refnet_model.diffusion_model.set_precision(precision)
+        # "auto": besides the per-network probes (unet.py), the CHAIN is measured before f16mx is kept -- see _auto_chain_probe
+        self._auto_chain = {"tolerance": self.AUTO_CHAIN_TOLERANCE, "steps": self.AUTO_CHAIN_STEPS, "done": {}, "busy": False, "report": None} if precision == "auto" else None
         return self
+
+    AUTO_CHAIN_TOLERANCE = 5e-5  # half the 1e-4 contract, like the per-network probe
+    AUTO_CHAIN_STEPS = 8
+
+    @property
+    def auto_chain_report(self) -> Optional[dict]:
+        """{"kept", "rel_l2_chain_vs_f16x3" (worst row), "steps", "tolerance", "modes"} of the last chain probe; None outside auto mode / before it ran"""
+        ac = getattr(self, "_auto_chain", None)
+        return None if ac is None else ac["report"]
+
+    def calibrate_precision(self) -> Optional[dict]:
+        """Auto mode: runs the per-network probes and the chain probe now (weights on a GPU) and returns the chain report."""
+        self._engine()
+        return self.auto_chain_report
+
+    @torch.no_grad()
+    def _auto_chain_probe(self, which: str) -> None:
+        """A per-network probe compares ONE forward; the sampler applies ~100 of them to its own output.  So where the networks settled on f16mx, eight
+        reverse steps (RefNet -> schedule -> z-MLP -> IllNet -> update, Philox noise from a fixed key, every row active: drm_drmnet_step) are run from
+        two seeded refmaps at 128x128 in the chosen modes and in f16x3; f16mx is kept only if every row of the final state agrees to `tolerance`,
+        otherwise BOTH networks run in f16x3 for these weights."""
+        from . import synth
+
+        ac = self._auto_chain
+        ill, ref = self.illnet_model.diffusion_model, self.refnet_model.diffusion_model
+        if ill.auto_report is None or ref.auto_report is None or "f16mx" not in (ill.precision, ref.precision):
+            return
+        key = (which, ill.__dict__["_auto"]["sig"], ref.__dict__["_auto"]["sig"])
+        if key in ac["done"]:
+            ac["report"] = ac["done"][key]
+            return
+        ac["busy"] = True
+        try:
+            dev = next(ill.parameters()).device
+            B, H, W = 2, 128, 128
+            x = synth.synth_refmaps(B, H, W, 4321).to(dev)
+            L = _lib.lib()
+            chosen = (ill.precision, ref.precision)
+
+            def chain():
+                h = self._engine_raw()
+                ws = self._ws.get(int(L.drm_drmnet_workspace_bytes(h, B, H, W)), dev)
+                Lr_k = x.clone()
+                with torch.cuda.device(dev):
+                    for i in range(ac["steps"]):
+                        _lib.check(L.drm_drmnet_step(h, Lr_k.data_ptr(), x.data_ptr(), None, B, i, None, 20261004, None, None, None, B, H, W, ws.data_ptr(),
+                                                     ws.numel(), _lib.stream_ptr(dev)))
+                return Lr_k.double().flatten(1)
+
+            a = chain()
+            ill._set_mode("f16x3")
+            ref._set_mode("f16x3")
+            b = chain()
+            rows = ((a - b).norm(dim=1) / b.norm(dim=1).clamp_min(1e-300)).tolist()
+            err = max(rows)
+            kept = err <= ac["tolerance"] and bool(torch.isfinite(a).all())
+            if kept:
+                ill._set_mode(chosen[0])
+                ref._set_mode(chosen[1])
+            else:
+                why = f"chain probe: {ac['steps']} DRMNet steps differ from f16x3 by {err:.2e} > {ac['tolerance']:.0e}"
+                ill.auto_override("f16x3", why)
+                ref.auto_override("f16x3", why)
+            ac["report"] = {"kept": kept, "rel_l2_chain_vs_f16x3": err, "rows": [float(f"{r:.3e}") for r in rows], "steps": ac["steps"], "tolerance": ac["tolerance"],
+                            "modes": {"illnet": chosen[0], "refnet": chosen[1]}, "probe": f"{B}x3x{H}x{W} seeded refmaps, {ac['steps']} reverse steps, worst row"}
+            ac["done"][key] = ac["report"]
+        finally:
+            ac["busy"] = False
 
     # ------------------------------------------------------------------ the device sampler
     def _engine(self):
+        """_engine_raw() behind the auto mode's chain probe (which may move both networks to f16x3 for the current weights)."""
+        h = self._engine_raw()
+        ac = getattr(self, "_auto_chain", None)
+        if ac is not None and not ac["busy"]:
+            self._auto_chain_probe(getattr(self, "_weight_set", "live"))
+            h = self._engine_raw()
+        return h
+
+    def _engine_raw(self):
         """The device sampler handle for the weight set that is live right now ("live" parameters, or the EMA shadow inside
         ``ema_scope``): one handle per set, rebuilt only when something it was built from changes."""
         which = getattr(self, "_weight_set", "live")

@@ -29,7 +29,7 @@ def estimate(DRMNet_model, ObsNet_model, input_img: torch.Tensor, input_normal: 
     if erode_kernel_size > 0:
         mask = erode_mask(mask, erode_kernel_size)
     # Making refmap from object image (estimate.py:52-58)
-    refmap_est, refmask = refmap_mask_make(input_img[mask], input_normal[mask], res=refmap_res, angle_threshold=np.pi / refmap_res / 2)
+    refmap_est, refmask = refmap_mask_make(input_img[mask], input_normal[mask], res=refmap_res, angle_threshold=np.pi / 128 / 2)  # (hard-coded in the reference too: scripts/estimate.py:57)
     # Inpainting refmap (estimate.py:63-81)
     batch = {"tag": [tag], "raw_refmap": refmap_est.permute(2, 0, 1)[None], "raw_refmask": refmask[None]}
     c, _, _ = ObsNet_model.get_cond_for_predict(batch, noise=hooks.get("cond_noise"))
@@ -76,7 +76,7 @@ def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_n
     for img, nrm, mask in zip(input_imgs, input_normals, masks):
         if erode_kernel_size > 0:
             mask = erode_mask(mask, erode_kernel_size)
-        rm, mk = refmap_mask_make(img[mask], nrm[mask], res=refmap_res, angle_threshold=np.pi / refmap_res / 2)
+        rm, mk = refmap_mask_make(img[mask], nrm[mask], res=refmap_res, angle_threshold=np.pi / 128 / 2)  # (scripts/estimate.py:57)
         refmaps.append(rm.permute(2, 0, 1))
         refmasks.append(mk)
     B = len(refmaps)

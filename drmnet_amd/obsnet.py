@@ -170,7 +170,65 @@ class LatentDiffusion(DDPM):
         """Conv arithmetic of the U-Net: "fp32" (exact fp32 MFMA), "f16x3" (split fp16, fp32-accurate, ~2.5x faster), "f16mx" (f16x3 with
         fp8 cross terms on the 3x3 convs: ~4e-5 per forward, ~3x faster) or "f16" (reduced precision)."""
         self.model.diffusion_model.set_precision(precision)
+        # "auto": the per-network probe (unet.py) + a chain probe before f16mx is kept (_auto_chain_probe)
+        self._auto_chain = {"tolerance": 5e-5, "steps": 8, "done": {}, "busy": False, "report": None} if precision == "auto" else None
         return self
+
+    @property
+    def auto_chain_report(self):
+        ac = getattr(self, "_auto_chain", None)
+        return None if ac is None else ac["report"]
+
+    def calibrate_precision(self):
+        """Auto mode: runs the network's probe and the chain probe now (weights on a GPU); returns the chain report."""
+        self.model.diffusion_model.calibrate_precision()
+        self._auto_chain_probe()
+        return self.auto_chain_report
+
+    @torch.no_grad()
+    def _auto_chain_probe(self) -> None:
+        """Where the U-Net's own probe settled on f16mx: the first eight steps of the DDIM-50 chain (eta = 1, Philox noise from a fixed key: the steps with the
+        largest 1 / sqrt(alpha_bar) amplification) from a seeded x_T and two seeded conditioning refmaps at 128x128, in f16mx and in f16x3; f16mx is kept
+        only if every row of the state agrees to `tolerance` (5e-5, half the contract), otherwise the network runs in f16x3 for these weights."""
+        ac = getattr(self, "_auto_chain", None)
+        unet = self.model.diffusion_model
+        if ac is None or ac["busy"] or unet.auto_report is None or unet.precision != "f16mx":
+            return
+        key = (unet._active_set, unet.__dict__["_auto"]["sig"])
+        if key in ac["done"]:
+            ac["report"] = ac["done"][key]
+            return
+        ac["busy"] = True
+        try:
+            from . import synth
+            from .ddim import DDIMSampler
+
+            dev = next(unet.parameters()).device
+            B, H, W = 2, 128, 128
+            cond = synth.synth_refmaps(B, H, W, 4321).to(dev)
+            x_T = torch.randn((B, 3, H, W), generator=torch.Generator().manual_seed(20261004)).to(dev)
+            smp = DDIMSampler(self)
+            smp.make_schedule(50, ddim_eta=1.0, verbose=False)
+
+            def chain():
+                x, _ = smp.ddim_sampling(cond, (B, 3, H, W), x_T=x_T, seed=20261004, num_steps=ac["steps"], log_every_t=0, verbose=False)
+                return x.double().flatten(1)
+
+            a = chain()
+            unet._set_mode("f16x3")
+            b = chain()
+            rows = ((a - b).norm(dim=1) / b.norm(dim=1).clamp_min(1e-300)).tolist()
+            err = max(rows)
+            kept = err <= ac["tolerance"] and bool(torch.isfinite(a).all())
+            if kept:
+                unet._set_mode("f16mx")
+            else:
+                unet.auto_override("f16x3", f"chain probe: {ac['steps']} DDIM steps differ from f16x3 by {err:.2e} > {ac['tolerance']:.0e}")
+            ac["report"] = {"kept": kept, "rel_l2_chain_vs_f16x3": err, "rows": [float(f"{r:.3e}") for r in rows], "steps": ac["steps"], "tolerance": ac["tolerance"],
+                            "probe": f"{B}x3x{H}x{W}: first {ac['steps']} steps of the DDIM-50 chain (eta 1), worst row"}
+            ac["done"][key] = ac["report"]
+        finally:
+            ac["busy"] = False
 
     def get_learned_conditioning(self, c):
         if self.cond_stage_forward is None:
@@ -234,6 +292,9 @@ class LatentDiffusion(DDPM):
         noise = None if noise is None else _lib.require_gpu_tensor(noise, "noise")
         unet = self.model.diffusion_model
         h = unet.engine_handle()
+        if getattr(self, "_auto_chain", None) is not None:  # auto mode: the chain probe may move the network to f16x3 for these weights
+            self._auto_chain_probe()
+            h = unet.engine_handle()
         L = _lib.lib()
         n, _, hh, ww = shape
         ws = self._ws.get(int(L.drm_sampler_workspace_bytes(h, n, hh, ww)), dev)

@@ -99,6 +99,8 @@ int drm_unet_use_set(drm_unet* net, int set);
  *       contract; tests hold it to 3e-2. */
 #define DRM_PREC_BF16 4
 int drm_unet_set_precision(drm_unet* net, int precision);
+/* drm_set_op_precision: the mode of the drm_op_* per-module entry points -- the library's only process-wide setting (an atomic word, read once at
+ * the entry of every drm_op_* call; set it before the calls it is meant for, not concurrently with them).  Networks and samplers carry their own. */
 int drm_set_op_precision(int precision);
 
 /* Workspace (activations, statistics, attention scores) needed by one forward of batch N at HxW. */
@@ -180,6 +182,13 @@ int drm_drmnet_sample(drm_drmnet* s, const float* LrK, const float* cond, const 
  *   x: [N,3,H,W] in = x_T, out = final x;  cond: [N,3,H,W];  noise: [steps,N,3,H,W] or NULL (Philox). */
 int drm_ddim_sample(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
                     const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same chain with the reference's `intermediates` (ddim.py:171-204: after the step of `index`, (img, pred_x0) are appended when
+ * index % log_every_t == 0 or at the first step): slot k of log_x / log_pred_x0 ([log_slots][N,3,H,W] each, device) receives the k-th appended
+ * pair, *n_logged (host) the number of pairs.  The steps that log are marked in the device step table, so graph replay applies unchanged. */
+int drm_ddim_sample_logged(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
+                           const float* noise, uint64_t seed, int log_every_t, float* log_x, float* log_pred_x0, int log_slots, int32_t* n_logged, int N,
+                           int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Ancestral DDPM (LatentDiffusion.p_sample via ObsNetDiffusion.p_sample_loop, ldm/models/diffusion/ddpm.py:1079-1167,
  * models/obsnet.py:500-564).  coef: float[T][5] (host) = sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,

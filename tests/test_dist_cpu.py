@@ -166,13 +166,60 @@ def test_live_traffic_falls_back_quietly(monkeypatch):
     monkeypatch.setattr(os.path, "exists", real_exists)
     monkeypatch.setattr(shutil, "which", lambda name: "/bin/false" if name == "rocprofv3" else None)
     calls = []
-    real_run = subprocess.run
+    real_popen = subprocess.Popen
 
-    def fake_run(cmd, **kw):
-        calls.append(cmd)
-        return real_run(["/bin/false"], **{k: v for k, v in kw.items() if k in ("stdout", "stderr", "timeout")})
+    def fake_popen(cmd, **kw):
+        calls.append((cmd, kw))
+        return real_popen(["/bin/false"], **{k: v for k, v in kw.items() if k in ("stdout", "stderr", "start_new_session")})
 
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("MASTER_PORT", "12345")
+    monkeypatch.setenv("DRM_BENCH_DIST", "1")
     assert bench.live_traffic(args, dom) == {}
-    assert calls and "--pmc" in calls[0] and "FETCH_SIZE" in calls[0] and "--no-live-traffic" in calls[0] and "--kernel-trace" in calls[0]
-    assert not any(f in calls[0] for f in ("--sys-trace", "-s", "--runtime-trace", "-r", "--hip-trace"))  # (counters in their own pass: the pool's rule)
+    cmd, kw = calls[0]
+    assert "--pmc" in cmd and "FETCH_SIZE" in cmd and "--no-live-traffic" in cmd and "--kernel-trace" in cmd
+    assert not any(f in cmd for f in ("--sys-trace", "-s", "--runtime-trace", "-r", "--hip-trace"))  # (counters in their own pass: the pool's rule)
+    # [r5, ADVICE r4] the child is a session of its own (a timeout kills rocprofv3 AND the python it started) and does not inherit the rank /
+    # rendezvous variables of a distributed parent
+    assert kw.get("start_new_session") is True
+    assert not any(k in kw["env"] for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "DRM_BENCH_DIST"))
+
+
+def test_pmc_child_kills_the_whole_process_group_on_timeout(monkeypatch, tmp_path):
+    """A child that outlives its budget: rocprofv3 would be killed alone by subprocess.run(timeout=...) and leave the profiled python holding the GPU."""
+    import argparse
+    import shutil
+    import subprocess
+    import time
+
+    import bench
+
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_")):
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("LD_PRELOAD", "")
+    marker = tmp_path / "grandchild.pid"
+    script = tmp_path / "fake_rocprofv3"
+    script.write_text(f"#!/bin/bash\n(sleep 30 & echo $! > {marker}; wait) \n")
+    script.chmod(0o755)
+    monkeypatch.setattr(shutil, "which", lambda name: str(script) if name == "rocprofv3" else None)
+    args = argparse.Namespace(precision="f16mx", batch=32, height=128, width=256)
+    t0 = time.time()
+    assert bench.pmc_child(args, ["FETCH_SIZE"], timeout_s=1) is None
+    assert time.time() - t0 < 10
+    pid = int(marker.read_text())
+
+    def running(p):  # (a killed process may linger as a zombie until its new parent reaps it)
+        try:
+            with open(f"/proc/{p}/stat") as f:
+                return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+        except OSError:
+            return False
+
+    for _ in range(40):
+        if not running(pid):
+            break
+        time.sleep(0.05)
+    assert not running(pid)  # the grandchild went with the group

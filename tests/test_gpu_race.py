@@ -18,3 +18,12 @@ def test_repetitions_are_identical_up_to_the_statistics_atomics():
     import race_screen
 
     assert race_screen.run_screen(6, cases=race_screen.QUICK, verbose=True) == 0
+
+
+def test_fused_splitk_handoff_across_xcds_many_repetitions():
+    """[r5, ADVICE r4] The fused split-K finish hands the slabs of a tile from eight workgroups on different XCDs to the last arriver through sc1
+    (agent-scope) stores and loads without cache-maintenance fences.  A stale slab read would be a silent wrong tile: 60 repetitions of a ResBlock
+    whose two 3x3 convs and 1x1 skip conv all take that path (42 output tiles x 8 splits), in both accurate split modes."""
+    import race_screen
+
+    assert race_screen.run_screen(60, cases=race_screen.SPLITK_XCD, precisions=("f16x3", "f16mx"), verbose=True) == 0

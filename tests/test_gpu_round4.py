@@ -255,6 +255,96 @@ def test_auto_precision_measures_the_loaded_weights(dev, rule, expect):
     assert m.set_precision("f16x3").auto_report is None  # an explicit mode leaves auto
 
 
+def test_auto_precision_probe_rows_and_cache(dev):
+    """[r5] The per-network probe is a batch (two inputs x three timesteps, worst row decides) and its reports are kept per (weight set, weight
+    signature): toggling between the live weights and an EMA shadow does not repeat a measurement."""
+    from drmnet_amd.unet import EncoderUNetModel
+
+    m = EncoderUNetModel(**ou.TINY_ENC_CFG)
+    synth.load_synth(m, 5)
+    m = m.to(dev).set_precision("auto")
+    rep = m.calibrate_precision()
+    assert len(rep["rows"]) == 6 and rep["rel_l2_f16mx_vs_f16x3"] == pytest.approx(max(rep["rows"]), rel=1e-3)
+    cache = m.__dict__["_auto"]["cache"]
+    assert len(cache) == 1
+    ema = [p.detach().clone() * 1.01 for p in m.param_tensors()]
+    m.use_weights("ema", ema)
+    rep_e = m.calibrate_precision()
+    assert len(cache) == 2 and rep_e is not rep
+    m.use_weights("live")
+    assert m.calibrate_precision() is rep  # the stored report, no new measurement
+    m.use_weights("ema", ema)
+    assert m.calibrate_precision() is rep_e and len(cache) == 2
+
+
+def test_auto_precision_chain_probe_overrules_the_single_forward_probe(dev):
+    """[r5, VERDICT r4 item 6] A per-network probe compares one forward; the samplers apply ~100 of them to their own output.  In auto mode DRMNet runs
+    eight reverse steps (ObsNet: eight DDIM steps) in the chosen modes and in f16x3 and keeps f16mx only if the chains agree to half the contract.
+    Weights that pass the single-forward probe but fail the chain probe (here: the chain tolerance put below what f16mx can deliver) must land on
+    f16x3 -- both networks -- while the per-network reports still show that each one passed on its own."""
+    from drmnet_amd.drmnet import DRMNet
+    from drmnet_amd.obsnet import ObsNetDiffusion
+
+    unet_t = {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(ou.TINY_UNET_CFG)}
+    enc_t = {"target": "ldm.modules.diffusionmodules.openaimodel.EncoderUNetModel", "params": dict(ou.TINY_ENC_CFG)}
+
+    def build():
+        m = DRMNet(illnet_config=unet_t, refnet_config=enc_t, max_timesteps=12, image_size=16, concat_mode=True, use_ema=False, gamma=0.9, epsilon=0.01, delta=0.025,
+                   z0=[1, 1, 1, 1, 0, 1], brdf_param_names=["p"] * 6)
+        synth.load_synth(m.illnet_model.diffusion_model, 21)
+        synth.load_synth(m.refnet_model.diffusion_model, 22)
+        zman = [(k, tuple(v.shape)) for k, v in m.illnet_model.z_emb_layer.state_dict().items()]
+        m.illnet_model.z_emb_layer.load_state_dict(synth.synth_state_dict(zman, synth.SEED_ZEMB))
+        return m.to(dev)
+
+    def auto(m, chain_tol):  # (the tiny networks amplify rounding noise more than the shipped ones: 1e-4 per forward in f16mx -- the test is about the mechanism,
+        m.AUTO_CHAIN_TOLERANCE = chain_tol  #  so the per-network bar is put where they pass it and the chain bar decides)
+        m.set_precision("auto")
+        for net in (m.illnet_model.diffusion_model, m.refnet_model.diffusion_model):
+            net.set_precision_auto(tolerance=1e-3)
+        return m
+
+    m = auto(build(), 1e-1)
+    rep = m.calibrate_precision()
+    ill, ref = m.illnet_model.diffusion_model, m.refnet_model.diffusion_model
+    print(f"chain probe (tiny DRMNet): {rep}; illnet {ill.auto_report}; refnet {ref.auto_report}")
+    assert rep["kept"] and rep["rel_l2_chain_vs_f16x3"] <= rep["tolerance"] and ill.precision == ref.precision == "f16mx"
+    LrK = synth.synth_refmaps(2, 16, 32, 5).to(dev)
+    out_auto = m.p_sample_loop(LrK, [LrK], [LrK], verbose=False, seed=3, early_exit=False)[0]
+    assert m.calibrate_precision() is rep  # measured once for these weights
+
+    # the case the chain probe exists for, as it occurs: every network passes its single-forward probe at 1e-3 (1.2e-4 / 1.7e-5), and eight steps of the
+    # undamped tiny sampler blow the f16mx-vs-f16x3 difference up to ~3e-3 -- the SAME bar applied to the chain sends both networks to f16x3
+    m2 = auto(build(), 1e-3)
+    rep2 = m2.calibrate_precision()
+    assert rep2["rel_l2_chain_vs_f16x3"] > 1e-3 > max(m2.illnet_model.diffusion_model.auto_report["rel_l2_f16mx_vs_f16x3"], m2.refnet_model.diffusion_model.auto_report["rel_l2_f16mx_vs_f16x3"])
+    ill2, ref2 = m2.illnet_model.diffusion_model, m2.refnet_model.diffusion_model
+    assert not rep2["kept"] and ill2.precision == ref2.precision == "f16x3"
+    assert ill2.auto_report["chosen"] == "f16x3" and "chain probe" in ill2.auto_report["overridden_by"]
+    assert ill2.auto_report["rel_l2_f16mx_vs_f16x3"] <= ill2.auto_report["tolerance"]  # ... although the single forward had passed
+    out_x3 = m2.p_sample_loop(LrK, [LrK], [LrK], verbose=False, seed=3, early_exit=False)[0]
+    m3 = build().set_precision("f16x3")
+    assert torch.equal(out_x3, m3.p_sample_loop(LrK, [LrK], [LrK], verbose=False, seed=3, early_exit=False)[0])  # it really runs in f16x3
+    assert rel_l2(out_auto.cpu(), out_x3.cpu()) < 1e-1  # (tiny undamped networks, 12 steps in f16mx: see above)
+
+    # ObsNet: the same mechanism on the first eight DDIM steps
+    obs = ObsNetDiffusion(unet_config=unet_t, linear_start=1e-4, linear_end=0.09, log_every_t=2000, timesteps=1000, first_stage_key="LrK",
+                          cond_stage_key="raw_refmap", padding_mode="noise", image_size=16, channels=3, concat_mode=True, ddim_steps=50,
+                          clip_denoised=False, masked_loss=False, use_ema=False)
+    synth.load_synth(obs.model.diffusion_model, 23)
+    obs = obs.to(dev).set_precision("auto")
+    obs.model.diffusion_model.set_precision_auto(tolerance=1e-3)
+    obs._auto_chain["tolerance"] = 1e-3
+    rep_o = obs.calibrate_precision()
+    print(f"chain probe (tiny ObsNet): {rep_o}")
+    assert rep_o is not None and rep_o["kept"] == (obs.model.diffusion_model.precision == "f16mx")
+    obs._auto_chain["done"].clear()
+    obs._auto_chain["tolerance"] = 1e-9
+    obs.model.diffusion_model._set_mode("f16mx")
+    obs._auto_chain_probe()
+    assert obs.model.diffusion_model.precision == "f16x3" and not obs.auto_chain_report["kept"]
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # Round 4, second half: the sparse-launch forms (batch-1 step).  AttentionBlock (openaimodel.py:278-333 over QKVAttentionLegacy
 # :365-381) on the short-sequence path -- qk_small_kernel, row softmax inside the P v GEMM, per-image range guard of q / k / v --

@@ -107,6 +107,29 @@ def test_ddim_sample_vs_reference_trace(dev, eta, precision):
     assert torch.equal(y, x)
 
 
+@pytest.mark.parametrize("log_every_t", [1, 10, 100])
+def test_ddim_intermediates_are_logged_as_the_reference_logs_them(dev, log_every_t):
+    """ddim.py:171-204: (img, pred_x0) are appended after the step of `index` when index % log_every_t == 0 or at the first step; x_T leads both lists.
+    The fixture holds the reference's per-step img record (log_every_t = 1)."""
+    from drmnet_amd.ddim import DDIMSampler
+
+    g = gold("ddim_trace_eta1")
+    m = tiny_obsnet(dev).set_precision("f16x3")
+    cond, x_T, noise = (torch.from_numpy(g[k]).to(dev) for k in ("cond", "x_T", "noise"))
+    s = DDIMSampler(m)
+    x, inter = s.sample(50, cond.shape[0], (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, log_every_t=log_every_t)
+    want = [j for j in range(50) if (49 - j) % log_every_t == 0 or j == 0]  # iteration numbers the reference logs
+    assert len(inter["x_inter"]) == len(inter["pred_x0"]) == 1 + len(want)
+    assert torch.equal(inter["x_inter"][0], x_T) and torch.equal(inter["pred_x0"][0], x_T)
+    for k, j in enumerate(want):
+        assert rel_l2(inter["x_inter"][1 + k].cpu(), g["x_inter"][j]) < 2e-5, (log_every_t, j)
+        assert bool(torch.isfinite(inter["pred_x0"][1 + k]).all())
+    assert torch.equal(inter["x_inter"][-1], x)  # index 0 is always logged: the last entry is the returned sample
+    # the logged chain is the unlogged chain
+    x2, _ = s.sample(50, cond.shape[0], (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, log_every_t=0)
+    assert torch.equal(x2, x)
+
+
 @pytest.mark.parametrize("precision", ACCURATE_MODES)
 def test_ddpm_ancestral_vs_reference_trace(dev, precision):
     g = gold("ddpm_trace")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # ObsNet forward (B = 32 @3x128x256: the T = 2048 attention path) under rocprofv3: kernel stats + the two HBM-traffic PMC passes.
 #   usage (GPU box): tools/prof_obsnet.sh <tag> [precision]   -> gpurun_out/prof_obsnet/<tag>_obsnet_<precision>_kernel_stats.csv,
-#                    <tag>_obsnet_<precision>_pmc_hbm_traffic.json, <tag>_obsnet_<precision>_bench.json   (precision defaults to bench.py's default, f16mx)
+#                    <tag>_obsnet_<precision>_pmc_hbm_traffic.json, <tag>_obsnet_<precision>_bench.json   (precision defaults to f16mx: what bench.py's default, `auto`, resolves to on the synthetic weights)
 tag=${1:-r04}
 prec=${2:-f16mx}
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"

@@ -34,6 +34,9 @@ CASES = [  # (kind, batch, cin, cout, h, w): persistent wide tiles, 192-wide til
     ("res", 2, 128, 128, 24, 40), ("attn", 32, 512, 512, 16, 32), ("attn", 8, 384, 384, 32, 64), ("attn", 32, 384, 384, 32, 64), ("attn", 5, 384, 384, 32, 32),
     ("attn", 32, 768, 768, 4, 8), ("attn", 1, 640, 640, 8, 8),
 ]
+# fused split-K finish with eight splits per tile on DIFFERENT XCDs (42 output tiles: the splits of a tile are 42 workgroup ids apart, 42 % 8 != 0) --
+# the hand-off the sc1 accesses carry without fences: screened at many repetitions by tests/test_gpu_race.py
+SPLITK_XCD = [("res", 1, 1344, 672, 16, 16), ("res", 2, 1344, 672, 16, 16)]
 QUICK = [("res", 32, 128, 128, 128, 256), ("res", 32, 768, 768, 4, 8), ("res", 1, 512, 512, 16, 16), ("res", 3, 256, 384, 12, 20), ("attn", 8, 384, 384, 32, 64),
          ("attn", 5, 384, 384, 32, 32), ("attn", 32, 512, 512, 16, 32)]
 

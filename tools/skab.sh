@@ -1,5 +1,7 @@
 #!/bin/bash
-# same-box comparison of split-K hand-off variants (DRM_SK_MODE builds of tools/build_variant.sh): the split / op parity tests and the batch-1 step
+# same-box comparison of the split-K hand-off forms: the product (sc1 accesses, no fences) against `tools/build_variant.sh skfenced "-DDRM_SK_FENCED=1"`
+# (plain accesses around agent-scope release / acquire fences): the split / op parity tests, the race screen and the batch-1 step
+#   usage: tools/skab.sh - drmnet_amd/csrc/_ab/libdrmnet_hip_skfenced.so
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 for lib in "$@"; do
   if [ "$lib" = "-" ]; then unset DRM_LIB_PATH; else export DRM_LIB_PATH="$PWD/$lib"; fi
