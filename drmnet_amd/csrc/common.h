@@ -89,6 +89,8 @@ struct ConvArgs {
   int stamp_block = 0, stamp_tile0 = 0;
 #endif
   double2* stat_out = nullptr;         // optional [N][Cout] (sum, sum of squares) of the OUTPUT, accumulated atomically (must be zeroed)
+  float* pool_out = nullptr;           // optional: the 2x2 average pool of the output, NHWC [N][H/2][W/2][Cout] (Downsample, openaimodel.py:154-160), written by the
+  double2* pool_stat = nullptr;        // same epilogue, with its [N][Cout] (sum, sum of squares) (zeroed) -- conv_split_pool_applicable says which launches can
   const float* w_inv_scale = nullptr;  // split-precision path: device scalar 2^-k undoing the weight pre-scaling
   int ld0 = 0;                         // channel stride of src0's pixels when it is a channel slice of a wider tensor (0 = C0)
   long long w_img_stride_f4 = 0;       // split 1x1 path: every image has its own packed weight set this many float4 apart (attention GEMMs)
@@ -106,6 +108,7 @@ int conv_split_ksplit(const ConvArgs& a);  // split-K factor the split kernels w
 bool conv_split_fused_finish(const ConvArgs& a);  // a split-K launch of this shape finishes its tiles itself (ConvArgs::split_ws / tile_ticket); else launch_splitk_reduce follows
 // deterministic second half of a split-K conv on maps of at most 256 pixels: out = sum of the slabs at `partial` (+ bias, emb, residual), statistics into a.stat_out
 int launch_splitk_reduce(const ConvArgs& a, const float* partial, hipStream_t s);
+bool conv_split_pool_applicable(const ConvArgs& a);  // this launch (shape fields set) can write ConvArgs::pool_out / pool_stat from its epilogue
 bool conv_split_fuses_stats();  // true when the active split kernel accumulates ConvArgs::stat_out in its epilogue
 size_t packed_conv_weight_split_floats(int taps, int CoutP, int CinP);
 // mx: the f16mx image (fp16 hi planes + e4m3 planes of hi and lo) for the 3x3 convs that run with ConvArgs::terms == 2

@@ -277,13 +277,18 @@ struct TilePos {
 // masks the epilogue's stores, residual reads and statistics per pixel).  A separate instantiation, so the shipped shapes' code is untouched.
 // SK: the instantiation split-K launches use (128-row x 32-channel tiles only): it carries the fused finish of the tile -- a separate
 // instantiation because its slab loads cost the narrow kernels 45 registers and one of their three waves per SIMD.
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false, bool SK = false>
+// POOL: the launch also writes the 2x2 average pool of its output and that tensor's statistics (ConvArgs::pool_out / pool_stat): the Downsample
+// that follows the last ResBlock of a level (openaimodel.py:154-160) re-read a map this epilogue has in registers (avgpool2_kernel: nine launches
+// and 2.4 GB of HBM traffic per batch-32 step).  A lane's 16 accumulator rows of a block are a 4 x 4 pixel patch: four pooled pixels, no exchange.
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false, bool SK = false, bool POOL = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
+  static_assert(!POOL || (C::SUB48 && C::TN == 1 && !RAG && !SK), "pooled output: one-image tiles of 4 x 8 patches");
   extern __shared__ float4 lds[];
   float4* As = lds;                                                   // [hl 2][s 2][h 2][HP]  16-byte entries
   float4* Bs = lds + C::A_F4;                                         // R x TPS x [hl 2][s 2][h 2][BN]
   double* lst = reinterpret_cast<double*>(lds + C::A_F4 + R * C::G_F4);  // [TN][BN][2]
+  [[maybe_unused]] double* lst2 = lst + C::TN * C::BN * 2;               // POOL: the pooled tensor's statistics, same shape
 
 #ifndef DRM_NO_KERNARG_TOUCH
   {
@@ -576,6 +581,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
   const bool st = a.stat_out != nullptr;
   if (st) {
     for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) lst[k] = 0.0;
+  }
+  if constexpr (POOL) {
+    for (int k = tid; k < C::TN * C::BN * 2; k += C::NTHR) lst2[k] = 0.0;
   }
 
   // ---- prologue: R-1 weight groups in flight (they may already belong to the next tile when a tile has < R-1 groups),
@@ -1072,6 +1080,33 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
           }
         }
         S2_STAMP(21 + 4 * (i * NT + c));  // values ready (bias / emb / residual landed and applied, statistics partials)
+        if constexpr (POOL) {
+          // v[4 g + k] = pixel (row g, column 4 h + k) of this block's 4 x 8 patch: pooled pixel (gy, 2 h + kx) = mean of rows 2 gy, 2 gy + 1 and
+          // columns 2 kx, 2 kx + 1, summed in avgpool2_kernel's order ((a + b) + c) + d
+          float pv[4];
+          float ps = 0.f, pq = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int gy = q >> 1, kx = q & 1;
+            pv[q] = (v[8 * gy + 2 * kx] + v[8 * gy + 2 * kx + 1] + v[8 * gy + 4 + 2 * kx] + v[8 * gy + 4 + 2 * kx + 1]) * 0.25f;
+            ps += pv[q];
+            pq += pv[q] * pv[q];
+          }
+          quad_transpose(pv[0], pv[1], pv[2], pv[3], r);  // -> pooled pixel (r & 3) of this lane's four channels
+          {
+            const int row0 = (wm * MT + i) * 32;
+            int img0, py0, px0;
+            C::rowmap(row0, img0, py0, px0);
+            const int q = r & 3;
+            const int ppy = ((cur.ty0 + py0) >> 1) + (q >> 1), ppx = ((cur.tx0 + px0) >> 1) + 2 * h + (q & 1);
+            const int cq4 = cur.co0 + (wn * NT + c) * 32 + (r & ~3);
+            const int n = cur.n0;
+            *reinterpret_cast<float4*>(&a.pool_out[(((size_t)n * (a.H >> 1) + ppy) * (a.W >> 1) + ppx) * a.Cout + cq4]) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            double* d2 = lst2 + (size_t)col * 2;
+            atomicAdd(d2, (double)ps);
+            atomicAdd(d2 + 1, (double)pq);
+          }
+        }
         if (a.out_nchw) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -1265,6 +1300,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #endif
         if (n < a.N) atomicAdd(reinterpret_cast<double*>(a.stat_out + (size_t)n * a.Cout + cur.co0) + rem, lst[k]);
         lst[k] = 0.0;
+        if constexpr (POOL) {
+          atomicAdd(reinterpret_cast<double*>(a.pool_stat + (size_t)n * a.Cout + cur.co0) + rem, lst2[k]);
+          lst2[k] = 0.0;
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -1284,13 +1323,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_split2_kernel(ConvArgs a)
 #endif
 }
 
-template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false, bool SK = false>
+template <int TAPS, int TH, int TW, int WM, int WN, int MT, int NT, int R, int TPS, int TERMS = 3, bool RAG = false, bool SK = false, bool POOL = false>
 static int launch_s2(const ConvArgs& a, hipStream_t s) {
   using C = S2Cfg<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS>;
-  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS, RAG, SK>;
+  auto kern = conv_split2_kernel<TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS, RAG, SK, POOL>;
   DRM_REQUIRE(RAG || (a.H % TH == 0 && a.W % TW == 0), "conv tile does not divide the map");
-  const size_t lds_bytes = (size_t)C::LDS_F4 * sizeof(float4);
-  static_assert(C::LDS_F4 * 16 <= 160 * 1024, "LDS budget");
+  DRM_REQUIRE(POOL == (a.pool_out != nullptr), "pooled output: only launches conv_split_pool_applicable accepts");
+  DRM_REQUIRE(!POOL || (a.pool_stat && a.stat_out && a.ksplit <= 1 && !a.out_nchw), "pooled output: needs both statistics tables, no split-K");
+  const size_t lds_bytes = (size_t)(C::LDS_F4 + (POOL ? C::ST_F4 : 0)) * sizeof(float4);
+  static_assert((C::LDS_F4 + (POOL ? C::ST_F4 : 0)) * 16 <= 160 * 1024, "LDS budget");
   const DeviceInfo* di = device_info();  // fails loudly on anything that is not an MI355X-shaped gfx950 (256 CUs, 160 KiB LDS)
   if (!di) return DRM_ERR_STATE;
   // the opt-in LDS size is a per-device function attribute: one bit per device ordinal, set idempotently (a racing second
@@ -1321,8 +1362,8 @@ static int launch_s2(const ConvArgs& a, hipStream_t s) {
     if (prof_enabled()) {  // the instantiation's name as rocprofv3 prints it: per-variant totals next to the per-family ones
       static const std::string vname = [] {
         char b[192];
-        snprintf(b, sizeof b, "void drm::conv_split2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS,
-                 RAG ? "true" : "false", SK ? "true" : "false");
+        snprintf(b, sizeof b, "void drm::conv_split2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s>", TAPS, TH, TW, WM, WN, MT, NT, R, TPS, TERMS,
+                 RAG ? "true" : "false", SK ? "true" : "false", POOL ? "true" : "false");
         return std::string(b);
       }();
       prof_variant(vname.c_str());
@@ -1424,6 +1465,9 @@ static int dispatch_s2_bn(const ConvArgs& a, hipStream_t s) {
     if (a.Cout % 192 == 0 && wgs(256, 192) >= 512) return launch_s2<TAPS, TH, TW, 4, 2, 2, 3, 3, 1, TERMS>(a, s);
   }
   if (a.Cout % 128 == 0 && (wgs(256, 128) >= S2_MIN_WIDE_TILES || (a.ksplit > 1 && !a.split_ws && conv_split_wide_ksplit(a) > 1))) {
+    if constexpr (TAPS == 9 && TH == 16 && TW == 16) {  // (conv_split_pool_applicable: exactly the launches that reach this line on 16 x 16 tiles)
+      if (a.pool_out) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS, false, false, true>(a, s);
+    }
     if constexpr (big_ok) return launch_s2<TAPS, TH, TW, 4, 2, 2, 2, RG, TPS, TERMS>(a, s);
     else return launch_s2<TAPS, TH4, TW4, 2, 2, 2, 2, 3, 1, TERMS>(a, s);
   }
@@ -1492,6 +1536,15 @@ extern template int dispatch_s2_tile<1, 3>(const ConvArgs&, hipStream_t);
 // in a second launch (5.8 us on the 4x8 maps of the batch-32 step, where the fused finish measured 1 % slower on the whole step; at batch 1 the maps
 // of 128 .. 1024 pixels are where the second launch cost 12 .. 22 us: 6.64 -> 6.0 ms per step with the fused finish).
 // ([r4] with the agent-scope hand-off the fused finish was tried on the smaller maps too: batch 1 4.79 vs 4.755 ms, batch 32 759 vs 763 steps/s -- the second launch stays)
+// mirrors dispatch_s2_tile / dispatch_s2_bn: a 3x3 launch on 16 x 16 pixel tiles that takes the 128-channel-wide 8-wave variant without split-K
+bool conv_split_pool_applicable(const ConvArgs& a) {
+  if (a.taps != 9 || a.out_nchw || a.w_img_stride_f4 != 0 || a.H % 16 != 0 || a.W % 16 != 0 || a.Cout % 128 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return false;
+  const long long rows = (long long)a.N * a.H * a.W;
+  auto wgs = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.Cout / bn); };
+  if ((a.terms == 3 || a.terms == 2) && a.Cout % 192 == 0 && wgs(256, 192) >= 512) return false;  // (the 192-wide variant goes first there)
+  return wgs(256, 128) >= S2_MIN_WIDE_TILES;
+}
+
 bool conv_split_fused_finish(const ConvArgs& a) { return a.H * a.W >= 128 && conv_split_wide_ksplit(a) <= 1; }
 
 // Split-K factor for a launch (1 = none).  Mirrors dispatch_s2_bn: only the 128-row x 32-channel fallback tiles qualify, when

@@ -148,7 +148,10 @@ struct Ctx {
 };
 Act new_act(Ctx& c, int C, int H, int W);
 int ensure_moments(Ctx& c, Act& a);
-int run_resblock(Ctx& c, const float* wbuf, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out);
+// pool (optional): the Downsample that follows this block -- when the out_layers conv can write the 2x2 average pool of `out` and its statistics from
+// its own epilogue (conv_split_pool_applicable) it does, and *pooled is set; otherwise the caller runs launch_avgpool2
+int run_resblock(Ctx& c, const float* wbuf, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out, Act* pool = nullptr,
+                 bool* pooled = nullptr);
 int run_attention(Ctx& c, const float* wbuf, const AttnLayer& a, Act& x, Act& out);
 // dispatches to the fp32 or the split-precision conv kernel; scale_off = the conv's pre-scaling slot in wbuf
 // `stats_for` (optional): the activation this conv completes -- its GroupNorm statistics are then accumulated in the epilogue

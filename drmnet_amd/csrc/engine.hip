@@ -424,7 +424,7 @@ static int arena_ok(const Ctx& c) {
   return DRM_ERR_WORKSPACE;
 }
 
-int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out) {
+int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, const float* emb_all, int emb_stride, Act& out, Act* pool, bool* pooled) {
   DRM_TRY(arena_ok(c));
   const int H = x0.H, W = x0.W;
   const int C0 = x0.C, C1 = x1 ? x1->C : 0;
@@ -454,6 +454,17 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
   b.src0 = h1.p; b.C0 = r.cout; b.N = c.N; b.H = H; b.W = W; b.taps = 9; b.Cout = r.cout; b.mx_site = 1;
   DRM_TRY(gn_params(c, h1, nullptr, Wb + r.n2_w, Wb + r.n2_b, sc2, sh2, nullptr, &b));
   float* ws2 = plan_splitk(c, b);
+  // the Downsample behind this block, from this conv's epilogue (decided on shapes and mode only: the sizing pass decides the same)
+  b.terms = (c.mx() && b.mx_site) ? 2 : c.terms();
+#ifdef DRM_NO_POOL_FUSION  // (A/B builds)
+  pool = nullptr;
+#endif
+  const bool fuse_pool = pool && b.ksplit <= 1 && c.split() && conv_split_fuses_stats() && conv_split_pool_applicable(b);
+  if (pooled) *pooled = fuse_pool;
+  if (fuse_pool) {
+    pool->mom_valid = true;
+    pool->mom_sums = true;
+  }
   float* wsk = nullptr;
   if (r.has_skip) {
     k.C0 = C0; k.C1 = C1; k.N = c.N; k.H = H; k.W = W; k.taps = 1; k.Cout = r.cout;
@@ -471,6 +482,11 @@ int run_resblock(Ctx& c, const float* Wb, const ResLayer& r, Act& x0, Act* x1, c
     b.gn_scale = sc2; b.gn_shift = sh2; b.silu = 1;
     b.w = Wb + r.c2_w; b.bias = Wb + r.c2_b;
     b.res = res; b.out = out.p;
+    if (fuse_pool) {
+      if (!pool->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(pool->mom, 0, (size_t)c.N * pool->C * sizeof(double2), c.s));
+      b.pool_out = pool->p;
+      b.pool_stat = pool->mom;
+    }
     DRM_TRY(run_conv(c, b, Wb, r.c2_s, &out, ws2));
   }
   c.ar->release(mark);
@@ -623,12 +639,19 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   }
   hs.push_back(h);
 
-  auto run_layers = [&](std::vector<Layer>& ls, Act* skip) -> int {
+  Act* pool_buf = nullptr;   // the output tensor of the Downsample that follows the block being run (allocated ahead of it) ...
+  bool pool_done = false;    // ... already written, statistics included, by that block's out_layers conv
+  auto run_layers = [&](std::vector<Layer>& ls, Act* skip, bool down_next = false) -> int {
     for (size_t li = 0; li < ls.size(); ++li) {
       Layer& l = ls[li];
       if (l.kind == Layer::RES) {
         Act* o = make(l.res.cout, h->H, h->W);
-        DRM_TRY(run_resblock(c, Wb, l.res, *h, (li == 0) ? skip : nullptr, emb_all, emb_total, *o));
+        Act* po = nullptr;
+        bool pooled = false;
+        if (down_next && li + 1 == ls.size() && h->H % 2 == 0 && h->W % 2 == 0) po = make(l.res.cout, h->H / 2, h->W / 2);
+        DRM_TRY(run_resblock(c, Wb, l.res, *h, (li == 0) ? skip : nullptr, emb_all, emb_total, *o, po, &pooled));
+        pool_buf = po;
+        pool_done = pooled;
         h = o;
       } else if (l.kind == Layer::ATTN) {
         Act* o = make(l.attn.ch, h->H, h->W);
@@ -636,8 +659,15 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
         h = o;
       } else if (l.kind == Layer::DOWN) {
         DRM_REQUIRE(!h->up, "downsample of an upsampled tensor");
-        Act* o = make(h->C, h->H / 2, h->W / 2);
+        Act* o = pool_buf ? pool_buf : make(h->C, h->H / 2, h->W / 2);
+        const bool done = pool_buf && pool_done;  // written by the producing conv's epilogue, statistics included
+        pool_buf = nullptr;
+        pool_done = false;
         DRM_TRY(arena_ok(c));
+        if (done) {
+          h = o;
+          continue;
+        }
         if (!c.dry()) {
           if (!o->mom_zeroed) DRM_HIP_CHECK(hipMemsetAsync(o->mom, 0, (size_t)N * o->C * sizeof(double2), s));
           DRM_TRY(launch_avgpool2(h->p, o->p, N, h->H, h->W, h->C, s, o->mom));  // pooled tensor + its GroupNorm sums in one pass
@@ -656,7 +686,8 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   };
 
   for (size_t b = 1; b < input_blocks.size(); ++b) {
-    DRM_TRY(run_layers(input_blocks[b], nullptr));
+    const bool down_next = b + 1 < input_blocks.size() && input_blocks[b + 1].size() == 1 && input_blocks[b + 1][0].kind == Layer::DOWN;
+    DRM_TRY(run_layers(input_blocks[b], nullptr, down_next));
     hs.push_back(h);
   }
   DRM_TRY(run_layers(middle, nullptr));
