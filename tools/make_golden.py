@@ -592,7 +592,7 @@ def make_estimate_chain(full=False):
     kernel = (torch.linalg.norm(kernel - k / 2, axis=0) <= k / 2)[None, None].float()
     inv_mask = torch.nn.functional.conv2d(inv_mask[None, None].float(), kernel, padding="same").bool()[0, 0]
     mask = torch.logical_and(mask, ~inv_mask)
-    refmap_est, refmask = refmap_mask_make(input_img[mask], input_normal[mask], res=res, angle_threshold=np.pi / res / 2)
+    refmap_est, refmask = refmap_mask_make(input_img[mask], input_normal[mask], res=res, angle_threshold=np.pi / 128 / 2)  # (the literal of scripts/estimate.py:57)
     batch = {"tag": ["sample"], "raw_refmap": refmap_est.permute(2, 0, 1)[None], "raw_refmask": refmask[None]}
     if full:
         torch.manual_seed(20261003)  # get_cond_for_predict fills the unobserved texels from torch's GLOBAL generator (models/obsnet.py:698): seeded, so that
