@@ -283,8 +283,8 @@ def cpu_baseline(args):
     return {"value": round(n / dt, 4), "unit": "U-Net denoise steps/sec", "cores": threads, "kind": "port",
             "sample": f"{n} DRMNet reverse steps (RefNet+IllNet, fp32) of 1 refmap 3x{H}x{W}, oracle/ on host CPU, {dt:.1f}s"}
 
-DOMINANT_VARIANTS = {"f16x3": "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3, false, false>",
-                     "f16mx": "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 2, false, false>"}
+DOMINANT_VARIANTS = {"f16x3": "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 3, false, false, false>",
+                     "f16mx": "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 2, false, false, false>"}
 
 
 def profile_variants(L) -> dict:

@@ -147,7 +147,7 @@ def test_live_traffic_falls_back_quietly(monkeypatch):
     import bench
 
     args = argparse.Namespace(precision="auto", batch=32, height=128, width=256)
-    dom = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 2, false, false>"
+    dom = "void drm::conv_split2_kernel<9, 16, 16, 4, 2, 2, 2, 2, 3, 2, false, false, false>"
     # under a profiler: no nested rocprofv3
     monkeypatch.setenv("ROCPROFILER_REGISTER_FORCE_LOAD", "1")
     assert bench.under_profiler() and bench.live_traffic(args, dom) == {}
