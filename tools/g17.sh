@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-AB_LINES=1 tools/ab_bench.sh - drmnet_amd/csrc/_ab/libdrmnet_hip_ws192.so drmnet_amd/csrc/_ab/libdrmnet_hip_ws384.so
+AB_LINES=1 tools/ab_bench.sh - drmnet_amd/csrc/_ab/libdrmnet_hip_ntstore.so
