@@ -29,5 +29,6 @@ for (n, cin, cout, h, w) in SHAPES:
     torch.cuda.synchronize(); L.drm_profile_enable(0)
     K = 5; ms, fl, by, cnt = (C.c_double*K)(), (C.c_double*K)(), (C.c_double*K)(), (C.c_int64*K)()
     L.drm_profile_collect(ms, fl, by, cnt)
-    print(f"{prec}{' ZERO operands' if zero else ''} resblock {cin}->{cout} @{h}x{w}: conv3x3 {ms[0]/cnt[0]:.3f} ms/launch ({fl[0]/ms[0]/1e9:.0f} TF)", flush=True)
+    print(f"{prec}{' ZERO operands' if zero else ''} resblock {cin}->{cout} @{h}x{w}: conv3x3 {ms[0]/cnt[0]:.3f} ms/launch ({fl[0]/ms[0]/1e9:.0f} TF)"
+          + (f"   conv1x1 (skip) {ms[1]/cnt[1]:.4f} ms/launch ({fl[1]/ms[1]/1e9:.0f} TF)" if cnt[1] else ""), flush=True)
     del x, P; torch.cuda.empty_cache()
