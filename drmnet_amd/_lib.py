@@ -24,7 +24,7 @@ SYMBOLS = [
     "drm_unet_create", "drm_unet_destroy", "drm_unet_param_count", "drm_unet_param_info", "drm_unet_load_params",
     "drm_unet_workspace_bytes", "drm_unet_forward",
     "drm_linear_forward", "drm_timestep_embedding", "drm_op_norm_act_conv", "drm_op_resblock", "drm_op_attention_block",
-    "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_step", "drm_drmnet_sample",
+    "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_set_batch_parts", "drm_drmnet_step", "drm_drmnet_sample",
     "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddim_sample_logged", "drm_ddpm_sample", "drm_randn",
     "drm_profile_enable", "drm_profile_reset", "drm_profile_collect", "drm_unet_set_precision", "drm_set_op_precision",
     "drm_refmap_workspace_bytes", "drm_refmap_mask_make", "drm_erode_mask",
@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
     L.drm_drmnet_destroy.restype = None
     L.drm_drmnet_workspace_bytes.argtypes = [vp, i32, i32, i32]
     L.drm_drmnet_workspace_bytes.restype = C.c_size_t
+    L.drm_drmnet_set_batch_parts.argtypes = [vp, i32]
+    L.drm_drmnet_set_batch_parts.restype = i32
     L.drm_drmnet_step.argtypes = [vp, fp, fp, vp, i32, i32, fp, C.c_uint64, fp, fp, vp, i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_drmnet_sample.argtypes = [vp, fp, fp, fp, fp, C.c_uint64, i32, fp, fp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_sampler_workspace_bytes.argtypes = [vp, i32, i32, i32]

@@ -352,6 +352,15 @@ size_t drm_drmnet_workspace_bytes(const drm_drmnet* s, int N, int H, int W) {
   return r;
 }
 
+int drm_drmnet_set_batch_parts(drm_drmnet* s, int parts) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(s != nullptr, "drm_drmnet_set_batch_parts: null handle");
+    DRM_REQUIRE(parts >= 1 && parts <= DrmnetSampler::PART_MAX, "drm_drmnet_set_batch_parts: 1 .. 4 parts");
+    s->s.parts = parts;
+    return DRM_OK;
+  });
+}
+
 int drm_drmnet_step(drm_drmnet* s, float* Lr_k, const float* LrK, const int32_t* rows, int n_active, int step, const float* noise,
                     uint64_t seed, float* zk_out, float* zK_out, int32_t* converged_out, int B, int H, int W, void* workspace,
                     size_t workspace_bytes, void* stream) {

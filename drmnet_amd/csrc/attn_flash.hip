@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_kernel(const float4* __rest
       constexpr int q = decltype(qc)::value;
       constexpr bool is_qk = q < NQK;
       constexpr int u = is_qk ? q / 2 : NCH + (q - NQK);           // DMA step of this unit inside the key tile
-      constexpr bool first_of_step = is_qk ? (q % 2 == 0) : true;
+      [[maybe_unused]] constexpr bool first_of_step = is_qk ? (q % 2 == 0) : true;
       constexpr bool last_of_step = is_qk ? (q % 2 == 1) : true;
       constexpr int u3 = (u + FA_AHEAD) % NSTEP;                    // the step whose DMA goes out at the top of this one
       int kt3 = kt + (u + FA_AHEAD >= NSTEP ? 1 : 0);  // (beyond the last tile: the first tile again -- a harmless re-read into a slot nobody reads any more)

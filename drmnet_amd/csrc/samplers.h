@@ -6,6 +6,7 @@ namespace drm {
 
 int launch_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s);
 
+struct StepBuffers;
 class DrmnetSampler {
  public:
   UNet* illnet = nullptr;
@@ -18,8 +19,20 @@ class DrmnetSampler {
   int sample(const float* LrK, const float* cond, const float* noise0, const float* step_noise, uint64_t seed, int early_exit, float* Lr0, float* zK, int32_t* K,
              int32_t* steps_done, int B, int H, int W, Arena& ar, hipStream_t s);
   ~DrmnetSampler();
+  // Batch parts of a step (1 = off): a step over n >= parts * part_min rows runs as `parts` independent row ranges on internal streams forked
+  // from and joined back into the caller's stream -- the sparse launches of one range (deep levels, small kernels: a third of the 256 CUs busy)
+  // overlap with the other range's.  Rows are independent (the reference's loop has no cross-row term); results are those of the ranges run one
+  // after the other.  Measured [r5]: two parts at 128 rows 927 vs 911 steps/s; at 32 rows 817 vs 852 (two ranges of 16 run one after the other
+  // reach 711: the levels below 64x128 drop to the narrow tiles, and the overlap does not win that back) -- hence part_min = 64.
+  static constexpr int PART_MAX = 4;
+  int parts = 2, part_min = 64;
 
  private:
+  int step_rows(float* Lr_k, const float* LrK, const int32_t* rows, int row0, int n, int i, const float* noise, uint64_t seed, const struct StepBuffers& b,
+                int j0, int B, int H, int W, Arena& ar, hipStream_t s);
+  hipStream_t part_stream[PART_MAX] = {};
+  hipEvent_t part_done[PART_MAX] = {};
+  hipEvent_t part_fork = nullptr;
   float* zemb = nullptr;  // z_emb_layer.{0,2,4}.{weight,bias}, device copy
   size_t zoff[6] = {0, 0, 0, 0, 0, 0};
   float* z0_dev = nullptr;

@@ -117,12 +117,12 @@ __global__ void drmnet_brdf_kernel(const float* __restrict__ z_out, const float*
 // Lr_k[rows[j]] += out[j] (+ delta * noise[rows[j]] unless converged)   (models/drmnet.py:763,822-825)
 __global__ void drmnet_update_kernel(float* __restrict__ Lr_k, const float* __restrict__ out, const int32_t* __restrict__ rows,
                                      const int32_t* __restrict__ conv, const float* __restrict__ noise, int n, size_t chw, float delta,
-                                     uint64_t seed, uint64_t noise_off) {
+                                     uint64_t seed, uint64_t noise_off, int row0) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)n * chw) return;
   const int j = (int)(i / chw);
   const size_t e = i % chw;
-  const int row = rows ? rows[j] : j;
+  const int row = rows ? rows[j] : row0 + j;
   const size_t g = (size_t)row * chw + e;
   float v = Lr_k[g] + out[i];
   if (!conv[j]) {
@@ -207,6 +207,11 @@ DrmnetSampler::~DrmnetSampler() {
   if (z0_dev) (void)hipFree(z0_dev);
   if (h_rows) (void)hipHostFree(h_rows);
   if (h_conv) (void)hipHostFree(h_conv);
+  for (int k = 0; k < PART_MAX; ++k) {
+    if (part_stream[k]) (void)hipStreamDestroy(part_stream[k]);
+    if (part_done[k]) (void)hipEventDestroy(part_done[k]);
+  }
+  if (part_fork) (void)hipEventDestroy(part_fork);
 }
 
 int DrmnetSampler::init(UNet* ill, UNet* ref, const float* const* zw, const drm_drmnet_cfg& c) {
@@ -214,6 +219,8 @@ int DrmnetSampler::init(UNet* ill, UNet* ref, const float* const* zw, const drm_
   DRM_REQUIRE(c.z_dim >= 1 && c.z_dim <= 8 && ref->desc.out_channels == c.z_dim, "z_dim must match RefNet out_channels (<= 8)");
   DRM_REQUIRE(c.max_timesteps >= 1, "max_timesteps");
   illnet = ill; refnet = ref; cfg = c;
+  if (const char* e = getenv("DRM_BATCH_PARTS")) parts = std::max(1, std::min((int)PART_MAX, atoi(e)));  // (A/B runs; the API is drm_drmnet_set_batch_parts)
+  if (const char* e = getenv("DRM_BATCH_PART_MIN")) part_min = std::max(1, atoi(e));                        // (tests: small batches through the forked form)
   const int mc = ill->desc.model_channels, hd = mc / 2;
   const size_t sizes[6] = {(size_t)hd * c.z_dim, (size_t)hd, (size_t)hd * hd, (size_t)hd, (size_t)mc * hd, (size_t)mc};
   size_t total = 0;
@@ -258,21 +265,78 @@ size_t DrmnetSampler::workspace_bytes(int N, int H, int W) const {
   Arena a2; a2.dry = true;
   if (illnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a1, nullptr) != DRM_OK) return 0;
   if (refnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a2, nullptr) != DRM_OK) return 0;
-  return base + std::max(a1.peak, a2.peak) + 256;
+  size_t need = std::max(a1.peak, a2.peak);
+  for (int np = 2; np <= std::min(std::min(parts, (int)PART_MAX), N / std::max(part_min, 1)); ++np) {  // the batch parts' workspace slices (step)
+    const int nmax = (N + np - 1) / np;
+    Arena p1; p1.dry = true;
+    Arena p2; p2.dry = true;
+    if (illnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nmax, H, W, p1, nullptr) != DRM_OK) return 0;
+    if (refnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nmax, H, W, p2, nullptr) != DRM_OK) return 0;
+    need = std::max(need, (size_t)np * ((std::max(p1.peak, p2.peak) + 511) & ~size_t(255)));
+  }
+  return base + need + 512;
 }
 
 // One reverse step on rows[0..n) (device indices, or null = identity)
 int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int n, int i, const float* noise, uint64_t seed, float* zk_out,
                         float* zK_out, int32_t* conv_out, int B, int H, int W, Arena& ar, hipStream_t s) {
   DRM_REQUIRE(n >= 1 && n <= B, "n_active");
+  const int zd = cfg.z_dim, mc = illnet->desc.model_channels;
+  const size_t chw = (size_t)3 * H * W;
+  StepBuffers b = step_buffers(ar, n, zd, mc, chw);  // per-row buffers of the whole step: a batch part works on its row range of them
+  if (ar.failed) { set_error("drmnet step: workspace too small"); return DRM_ERR_WORKSPACE; }
+  const int np = std::min(std::min(parts, (int)PART_MAX), n / std::max(part_min, 1));
+  if (np < 2 || ar.dry) {
+    DRM_TRY(step_rows(Lr_k, LrK, rows, 0, n, i, noise, seed, b, 0, B, H, W, ar, s));
+  } else {
+    // fork: every part waits for the caller's stream, runs its rows on its own stream and workspace slice, and the caller's stream waits for all
+    if (!part_fork) DRM_HIP_CHECK(hipEventCreateWithFlags(&part_fork, hipEventDisableTiming));
+    for (int k = 0; k < np; ++k) {
+      if (!part_stream[k]) DRM_HIP_CHECK(hipStreamCreateWithFlags(&part_stream[k], hipStreamNonBlocking));
+      if (!part_done[k]) DRM_HIP_CHECK(hipEventCreateWithFlags(&part_done[k], hipEventDisableTiming));
+    }
+    const bool serial = prof_enabled();  // the launch profiler brackets every launch with events: isolated durations need one stream
+    const size_t room = ((ar.cap - ar.off) / np) & ~size_t(255);
+    if (!serial) DRM_HIP_CHECK(hipEventRecord(part_fork, s));
+    int rc = DRM_OK;
+    for (int k = 0; k < np && rc == DRM_OK; ++k) {
+      const int j0 = (int)((long long)n * k / np), j1 = (int)((long long)n * (k + 1) / np);
+      Arena sub;
+      sub.base = ar.base + ((ar.off + 255) & ~size_t(255)) + (size_t)k * room;
+      sub.cap = room;
+      hipStream_t ps = serial ? s : part_stream[k];
+      if (!serial) DRM_HIP_CHECK(hipStreamWaitEvent(ps, part_fork, 0));
+      rc = step_rows(Lr_k, LrK, rows ? rows + j0 : nullptr, rows ? 0 : j0, j1 - j0, i, noise, seed, b, j0, B, H, W, sub, ps);
+      if (sub.failed && rc == DRM_OK) { set_error("drmnet step: workspace too small for the batch parts"); rc = DRM_ERR_WORKSPACE; }
+      if (!serial) {  // (joined even after a failed part: the caller's stream must not run ahead of work already queued)
+        (void)hipEventRecord(part_done[k], ps);
+        (void)hipStreamWaitEvent(s, part_done[k], 0);
+      }
+    }
+    if (rc != DRM_OK) return rc;
+  }
+  if (zk_out) DRM_HIP_CHECK(hipMemcpyAsync(zk_out, b.zk, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (zK_out) DRM_HIP_CHECK(hipMemcpyAsync(zK_out, b.zKc, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (conv_out) DRM_HIP_CHECK(hipMemcpyAsync(conv_out, b.conv, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  last = b.conv;
+  last_zKc = b.zKc;
+  return DRM_OK;
+}
+
+// rows [j0, j0 + n) of a step's row list (rows: that range of the device indices, or null = the identity rows row0 .. row0 + n)
+int DrmnetSampler::step_rows(float* Lr_k, const float* LrK, const int32_t* rows, int row0, int n, int i, const float* noise, uint64_t seed,
+                             const StepBuffers& bb, int j0, int B, int H, int W, Arena& ar, hipStream_t s) {
   const int zd = cfg.z_dim, mc = illnet->desc.model_channels, hd = mc / 2;
   const size_t chw = (size_t)3 * H * W;
-  StepBuffers b = step_buffers(ar, n, zd, mc, chw);
-  if (ar.failed) { set_error("drmnet step: workspace too small"); return DRM_ERR_WORKSPACE; }
+  StepBuffers b = bb;
+  b.z_out += (size_t)j0 * zd; b.zk += (size_t)j0 * zd; b.dz += (size_t)j0 * zd; b.zKc += (size_t)j0 * zd;
+  b.h1 += (size_t)j0 * hd; b.h2 += (size_t)j0 * hd; b.temb += (size_t)j0 * mc; b.tf += j0; b.conv += j0; b.eps += (size_t)j0 * chw;
+  float* x = Lr_k + (size_t)row0 * chw;  // identity rows: the range starts at row0 (row lists index the whole tensors)
+  const float* c = LrK + (size_t)row0 * chw;
   const size_t net_mark = ar.mark();
   // RefNet(cat[Lr_k, LrK], timesteps = i)     (models/drmnet.py:453, :376-388)
   DRM_TRY(fill_f32(b.tf, n, (float)i, s));
-  DRM_TRY(refnet->forward(Lr_k, 3, LrK, 3, rows, nullptr, nullptr, b.tf, b.z_out, n, H, W, ar, s));
+  DRM_TRY(refnet->forward(x, 3, c, 3, rows, nullptr, nullptr, b.tf, b.z_out, n, H, W, ar, s));
   ar.release(net_mark);
   const float gpow = (float)std::exp((double)i * std::log(cfg.gamma));
   hipLaunchKernelGGL(drmnet_brdf_kernel, dim3((n + 63) / 64), dim3(64), 0, s, b.z_out, z0_dev, n, zd, gpow, cfg.epsilon, b.zk, b.dz, b.zKc, b.conv);
@@ -282,17 +346,12 @@ int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int 
   DRM_TRY(launch_linear(b.h1, zemb + zoff[2], zemb + zoff[3], b.h2, n, hd, hd, 0, 1, s));
   DRM_TRY(launch_linear(b.h2, zemb + zoff[4], zemb + zoff[5], b.temb, n, hd, mc, 0, 1, s));
   // IllNet(cat[Lr_k, LrK], t_emb)             (models/drmnet.py:455-456, :54-61)
-  DRM_TRY(illnet->forward(Lr_k, 3, LrK, 3, rows, b.temb, nullptr, nullptr, b.eps, n, H, W, ar, s));
+  DRM_TRY(illnet->forward(x, 3, c, 3, rows, b.temb, nullptr, nullptr, b.eps, n, H, W, ar, s));
   ar.release(net_mark);
   const size_t total = (size_t)n * chw;
   hipLaunchKernelGGL(drmnet_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Lr_k, b.eps, rows, b.conv, noise, n, chw,
-                     cfg.delta, seed, (uint64_t)(i + 1) * (uint64_t)B * chw);
+                     cfg.delta, seed, (uint64_t)(i + 1) * (uint64_t)B * chw, row0);
   DRM_HIP_CHECK(hipGetLastError());
-  if (zk_out) DRM_HIP_CHECK(hipMemcpyAsync(zk_out, b.zk, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if (zK_out) DRM_HIP_CHECK(hipMemcpyAsync(zK_out, b.zKc, (size_t)n * zd * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if (conv_out) DRM_HIP_CHECK(hipMemcpyAsync(conv_out, b.conv, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  last = b.conv;
-  last_zKc = b.zKc;
   return DRM_OK;
 }
 

@@ -314,8 +314,17 @@ class DRMNet(nn.Module):
         torch.cuda.current_stream(zp[0].device).synchronize()
         with torch.cuda.device(zp[0].device):
             _lib.check(_lib.lib().drm_drmnet_create(hi, hr, _lib.ptr_array(zp), C.byref(cfg), C.byref(h)))
+        if getattr(self, "_batch_parts", None) is not None:
+            _lib.check(_lib.lib().drm_drmnet_set_batch_parts(h, int(self._batch_parts)))
         self._samplers[which] = (h, sig)
         return h
+
+    def set_batch_parts(self, parts: int):
+        """Row ranges a reverse step is forked into on internal streams (drm_drmnet_set_batch_parts; library default 2 from 64 rows per part, 1 = off)."""
+        self._batch_parts = int(parts)
+        for h, _ in getattr(self, "_samplers", {}).values():
+            _lib.check(_lib.lib().drm_drmnet_set_batch_parts(h, int(parts)))
+        return self
 
     def _free_sampler(self, which=None):
         for k in ([which] if which else list(getattr(self, "_samplers", {}))):

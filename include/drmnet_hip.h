@@ -155,6 +155,11 @@ typedef struct drm_drmnet drm_drmnet;
 int drm_drmnet_create(drm_unet* illnet, drm_unet* refnet, const float* const* zemb, const drm_drmnet_cfg* cfg, drm_drmnet** out);
 void drm_drmnet_destroy(drm_drmnet* s);
 size_t drm_drmnet_workspace_bytes(const drm_drmnet* s, int N, int H, int W);
+/* Batch parts of a reverse step (default 2; 1 = off; at most 4): a step over at least 64 rows per part runs its row ranges on internal streams
+ * forked from and joined back into `stream`, so the sparse launches of one range (deep levels, small kernels) overlap with the other's.  The rows
+ * of the reference's loop are independent (models/drmnet.py:809-839): results are those of the ranges run one after the other.  Call before
+ * drm_drmnet_workspace_bytes (the workspace covers the parts' slices). */
+int drm_drmnet_set_batch_parts(drm_drmnet* s, int parts);
 
 /* One reverse step on the active rows (DRMNet.p_mean_variance + the loop body, models/drmnet.py:752-770,809-839):
  *   z_out = RefNet(cat[Lr_k, LrK], i); zk = clamp(z0 + gamma^i (z_out - z0)); out = IllNet(cat[Lr_k, LrK], z_emb(zk - z0));

@@ -76,6 +76,38 @@ def test_drmnet_loop_without_early_exit_and_philox(dev):
     assert a[2].tolist() == [int(g["max_timesteps"])] * LrK.shape[0] and torch.isnan(a[1]).all()
 
 
+@pytest.mark.parametrize("parts", [2, 3])
+def test_drmnet_step_over_forked_batch_parts_equals_the_single_stream_step(dev, parts, monkeypatch):
+    """drm_drmnet_set_batch_parts: the row ranges of a step on internal streams (forked from / joined into the caller's stream) give what the
+    single-stream step gives -- through the reference trace (rows leave the loop at different steps: the ranges shrink and collapse to one), the
+    host-driven per-step entry point, and a batch that is not a multiple of the parts.  The parts engage from 64 rows each in the product;
+    DRM_BATCH_PART_MIN (read when the sampler is created) lets a tiny batch through them."""
+    g = gold("drmnet_loop_b")
+    LrK = torch.from_numpy(g["LrK"]).to(dev)
+    n0 = torch.from_numpy(g["noise0"]).to(dev)
+    sn = torch.from_numpy(g["step_noise"]).to(dev)
+    ref = tiny_drmnet(g, dev).set_precision("f16x3")
+    Lr0_1, zK_1, K_1 = ref.p_sample_loop(LrK, [LrK], [LrK], verbose=False, noise0=n0, step_noise=sn)
+    monkeypatch.setenv("DRM_BATCH_PART_MIN", "1")
+    monkeypatch.setenv("DRM_BATCH_PARTS", str(parts))
+    m = tiny_drmnet(g, dev).set_precision("f16x3")
+    Lr0, zK, K = m.p_sample_loop(LrK, [LrK], [LrK], verbose=False, noise0=n0, step_noise=sn)
+    assert K.cpu().tolist() == g["K"].tolist() == K_1.cpu().tolist()
+    # (a range of 1-2 rows takes other tile shapes / split-K forms than the whole batch: equal to f16x3 rounding, not bitwise)
+    assert rel_l2(Lr0.cpu(), g["Lr0"]) < 1e-4 and rel_l2(Lr0.cpu(), Lr0_1.cpu()) < 2e-5
+    assert np.allclose(np.nan_to_num(zK.cpu().numpy()), np.nan_to_num(zK_1.cpu().numpy()), atol=1e-5)
+    Lr0b, _, Kb, _ = m.p_sample_loop(LrK, [LrK], [LrK], return_intermediates=True, verbose=False, log_every_k=1, noise0=n0, step_noise=sn)
+    assert Kb.cpu().tolist() == g["K"].tolist() and rel_l2(Lr0b.cpu(), Lr0_1.cpu()) < 2e-5
+    # identity rows (no row list), Philox noise, 7 rows over the parts: same as the single-stream sampler with the same seed
+    x7 = synth.synth_refmaps(7, 16, 16, synth.SEED_INPUT).to(dev)
+    # (the first steps are compared: this tiny random pair of networks amplifies a last-bit difference step by step)
+    a = m.p_sample_loop(x7, [x7], [x7], return_intermediates=True, verbose=False, log_every_k=1, seed=11, early_exit=False)
+    b = ref.p_sample_loop(x7, [x7], [x7], return_intermediates=True, verbose=False, log_every_k=1, seed=11, early_exit=False)
+    errs = [rel_l2(p.cpu(), q.cpu()) for p, q in zip(a[3]["Lrk_inter"], b[3]["Lrk_inter"])]
+    print("forked vs single-stream, 7 identity rows, per step:", " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs[:3]) < 5e-6 and torch.isfinite(a[0]).all()
+
+
 def tiny_obsnet(dev):
     from drmnet_amd.obsnet import ObsNetDiffusion
 
