@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One step of a rocprofv3 --kernel-trace of bench.py (the launches between the last pack_input kernels), aggregated per kernel [and grid]:
+"""One step of a rocprofv3 --kernel-trace of bench.py (the launches between the last pack_input kernels / RefNet stem launches), aggregated per kernel [and grid]:
 launch count, total and average duration, the step's span and busy time (span - busy = gaps between kernels).
     usage: tools/step_trace.py <..._kernel_trace.csv> [g = split by grid] [rows]
     e.g.   rocprofv3 --kernel-trace --stats -d out -o b1 --output-format csv -- python3 bench.py --batch 1 --height 128 --width 128 ...
@@ -8,7 +8,10 @@ import csv,collections,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 idx=[i for i,r in enumerate(rows) if 'pack_input' in r['Kernel_Name']]
-a,b=idx[-3],idx[-1]
+if len(idx)>=3: a,b=idx[-3],idx[-1]
+else:  # round 5 on: the stem conv reads the NCHW inputs itself -- a step starts at RefNet's stem launch (two stem launches per step)
+    idx=[i for i,r in enumerate(rows) if 'stem_conv_kernel' in r['Kernel_Name']]
+    a,b=idx[-4],idx[-2]
 t0=int(rows[a]['Start_Timestamp'])
 agg=collections.defaultdict(lambda:[0,0.0])
 tot=0
