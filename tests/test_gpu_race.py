@@ -27,3 +27,32 @@ def test_fused_splitk_handoff_across_xcds_many_repetitions():
     import race_screen
 
     assert race_screen.run_screen(60, cases=race_screen.SPLITK_XCD, precisions=("f16x3", "f16mx"), verbose=True) == 0
+
+
+def test_forked_row_ranges_of_the_drmnet_step_many_repetitions(monkeypatch):
+    """[r5] drm_drmnet_set_batch_parts runs the row ranges of a reverse step on internal streams that share the weights, the caller's tensors and one
+    workspace (disjoint slices).  A slice overlap, a range running ahead of the fork or the caller's stream running ahead of the join would show as a
+    different state on some repetition: 40 steps x 3 parts on 9 rows, every repetition from the same state, all equal to the first up to the
+    statistics atomics."""
+    import numpy as np
+
+    from conftest import gold, rel_l2
+    from test_gpu_samplers import tiny_drmnet
+
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("DRM_BATCH_PART_MIN", "1")
+    monkeypatch.setenv("DRM_BATCH_PARTS", "3")
+    g = gold("drmnet_loop_b")
+    m = tiny_drmnet(g, dev).set_precision("f16mx")
+    from drmnet_amd import synth
+
+    x = synth.synth_refmaps(9, 16, 16, synth.SEED_INPUT).to(dev)
+    first = None
+    for rep in range(40):
+        out = m.p_sample_loop(x, [x], [x], return_intermediates=True, verbose=False, log_every_k=1, seed=5, early_exit=False)
+        state = out[3]["Lrk_inter"][3].cpu()  # after three steps (later steps amplify last-bit differences of this tiny random pair of networks)
+        if first is None:
+            first = state
+        else:
+            assert rel_l2(state, first) < 2e-6, f"repetition {rep} differs"
+    assert np.isfinite(first.numpy()).all()
