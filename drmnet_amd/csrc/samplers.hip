@@ -285,7 +285,9 @@ int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int 
   const size_t chw = (size_t)3 * H * W;
   StepBuffers b = step_buffers(ar, n, zd, mc, chw);  // per-row buffers of the whole step: a batch part works on its row range of them
   if (ar.failed) { set_error("drmnet step: workspace too small"); return DRM_ERR_WORKSPACE; }
-  const int np = std::min(std::min(parts, (int)PART_MAX), n / std::max(part_min, 1));
+  // (not under the launch profiler: it brackets every launch with events on the launch stream, and a bracket on one part's stream would include
+  //  the other part's kernels -- the profiled pass runs the whole batch on the caller's stream)
+  const int np = prof_enabled() ? 1 : std::min(std::min(parts, (int)PART_MAX), n / std::max(part_min, 1));
   if (np < 2 || ar.dry) {
     DRM_TRY(step_rows(Lr_k, LrK, rows, 0, n, i, noise, seed, b, 0, B, H, W, ar, s));
   } else {
@@ -295,7 +297,7 @@ int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int 
       if (!part_stream[k]) DRM_HIP_CHECK(hipStreamCreateWithFlags(&part_stream[k], hipStreamNonBlocking));
       if (!part_done[k]) DRM_HIP_CHECK(hipEventCreateWithFlags(&part_done[k], hipEventDisableTiming));
     }
-    const bool serial = prof_enabled();  // the launch profiler brackets every launch with events: isolated durations need one stream
+    const bool serial = false;
     const size_t room = ((ar.cap - ar.off) / np) & ~size_t(255);
     if (!serial) DRM_HIP_CHECK(hipEventRecord(part_fork, s));
     int rc = DRM_OK;
