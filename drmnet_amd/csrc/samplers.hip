@@ -297,23 +297,20 @@ int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int 
       if (!part_stream[k]) DRM_HIP_CHECK(hipStreamCreateWithFlags(&part_stream[k], hipStreamNonBlocking));
       if (!part_done[k]) DRM_HIP_CHECK(hipEventCreateWithFlags(&part_done[k], hipEventDisableTiming));
     }
-    const bool serial = false;
     const size_t room = ((ar.cap - ar.off) / np) & ~size_t(255);
-    if (!serial) DRM_HIP_CHECK(hipEventRecord(part_fork, s));
+    DRM_HIP_CHECK(hipEventRecord(part_fork, s));
     int rc = DRM_OK;
     for (int k = 0; k < np && rc == DRM_OK; ++k) {
       const int j0 = (int)((long long)n * k / np), j1 = (int)((long long)n * (k + 1) / np);
       Arena sub;
       sub.base = ar.base + ((ar.off + 255) & ~size_t(255)) + (size_t)k * room;
       sub.cap = room;
-      hipStream_t ps = serial ? s : part_stream[k];
-      if (!serial) DRM_HIP_CHECK(hipStreamWaitEvent(ps, part_fork, 0));
+      hipStream_t ps = part_stream[k];
+      DRM_HIP_CHECK(hipStreamWaitEvent(ps, part_fork, 0));
       rc = step_rows(Lr_k, LrK, rows ? rows + j0 : nullptr, rows ? 0 : j0, j1 - j0, i, noise, seed, b, j0, B, H, W, sub, ps);
       if (sub.failed && rc == DRM_OK) { set_error("drmnet step: workspace too small for the batch parts"); rc = DRM_ERR_WORKSPACE; }
-      if (!serial) {  // (joined even after a failed part: the caller's stream must not run ahead of work already queued)
-        (void)hipEventRecord(part_done[k], ps);
-        (void)hipStreamWaitEvent(s, part_done[k], 0);
-      }
+      (void)hipEventRecord(part_done[k], ps);  // (joined even after a failed part: the caller's stream must not run ahead of work already queued)
+      (void)hipStreamWaitEvent(s, part_done[k], 0);
     }
     if (rc != DRM_OK) return rc;
   }
