@@ -24,8 +24,8 @@ SYMBOLS = [
     "drm_unet_create", "drm_unet_destroy", "drm_unet_param_count", "drm_unet_param_info", "drm_unet_load_params",
     "drm_unet_workspace_bytes", "drm_unet_forward",
     "drm_linear_forward", "drm_timestep_embedding", "drm_op_norm_act_conv", "drm_op_resblock", "drm_op_attention_block",
-    "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_set_batch_parts", "drm_drmnet_step", "drm_drmnet_sample",
-    "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddim_sample_logged", "drm_ddpm_sample", "drm_randn",
+    "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_set_batch_parts", "drm_drmnet_set_batch_part_min", "drm_drmnet_step", "drm_drmnet_sample",
+    "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddim_sample_logged", "drm_ddpm_sample", "drm_ddim_sample_masked", "drm_ddpm_sample_masked", "drm_randn",
     "drm_profile_enable", "drm_profile_reset", "drm_profile_collect", "drm_unet_set_precision", "drm_set_op_precision",
     "drm_refmap_workspace_bytes", "drm_refmap_mask_make", "drm_erode_mask",
     "drm_unet_load_params_set", "drm_unet_use_set", "drm_set_graph_replay", "drm_graph_launches",
@@ -41,11 +41,41 @@ class UNetDesc(C.Structure):
     ]
 
 
+class MaskBlend(C.Structure):  # drm_mask_blend
+    _fields_ = [("mask", C.c_void_p), ("mask_channels", C.c_int32), ("x0", C.c_void_p), ("qcoef", C.POINTER(C.c_float)), ("qnoise", C.c_void_p), ("when", C.c_int32)]
+
+
 class DrmnetCfg(C.Structure):
     _fields_ = [
         ("z_dim", C.c_int32), ("max_timesteps", C.c_int32), ("gamma", C.c_double), ("epsilon", C.c_float), ("delta", C.c_float),
         ("z0", C.c_float * 8),
     ]
+
+
+def make_mask_blend(mask, x0, qcoef, qnoise, when: int, img_shape):
+    """drm_mask_blend for a chain on `img_shape` [N,C,H,W]: mask [N,1|C,H,W] (or broadcastable [1|N,1|C,H,W]), x0 like img, qcoef float32 [steps,2] (numpy, host),
+    qnoise [steps,N,C,H,W] or None.  Returns (struct, keep-alive tuple)."""
+    import numpy as np
+    import torch
+
+    n, c, h, w = img_shape
+    x0 = require_gpu_tensor(x0, "x0").float().contiguous()
+    if tuple(x0.shape) != tuple(img_shape):
+        raise RuntimeError(f"x0 must be {tuple(img_shape)}")
+    mask = require_gpu_tensor(mask, "mask").float()
+    if mask.dim() != 4 or mask.shape[2:] != x0.shape[2:] or mask.shape[1] not in (1, c) or mask.shape[0] not in (1, n):
+        raise RuntimeError(f"mask must be [N or 1, 1 or {c}, {h}, {w}]")
+    mask = mask.expand(n, mask.shape[1], h, w).contiguous()
+    qc = np.ascontiguousarray(np.asarray(qcoef, dtype=np.float32))
+    qn = None if qnoise is None else require_gpu_tensor(qnoise, "mask_noise").float().contiguous()
+    if qn is not None and tuple(qn.shape) != (qc.shape[0],) + tuple(img_shape):
+        raise RuntimeError(f"mask_noise must be [steps={qc.shape[0]}, N, C, H, W]")
+    b = MaskBlend()
+    b.mask, b.mask_channels, b.x0 = mask.data_ptr(), int(mask.shape[1]), x0.data_ptr()
+    b.qcoef = qc.ctypes.data_as(C.POINTER(C.c_float))
+    b.qnoise = None if qn is None else qn.data_ptr()
+    b.when = int(when)
+    return b, (mask, x0, qc, qn)
 
 
 _lib: Optional[C.CDLL] = None
@@ -87,6 +117,8 @@ def lib() -> C.CDLL:
     L.drm_drmnet_workspace_bytes.restype = C.c_size_t
     L.drm_drmnet_set_batch_parts.argtypes = [vp, i32]
     L.drm_drmnet_set_batch_parts.restype = i32
+    L.drm_drmnet_set_batch_part_min.argtypes = [vp, i32]
+    L.drm_drmnet_set_batch_part_min.restype = i32
     L.drm_drmnet_step.argtypes = [vp, fp, fp, vp, i32, i32, fp, C.c_uint64, fp, fp, vp, i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_drmnet_sample.argtypes = [vp, fp, fp, fp, fp, C.c_uint64, i32, fp, fp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_sampler_workspace_bytes.argtypes = [vp, i32, i32, i32]
@@ -95,6 +127,9 @@ def lib() -> C.CDLL:
     L.drm_ddim_sample_logged.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, fp, fp, i32, C.POINTER(C.c_int32),
                                          i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_ddpm_sample.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_ddim_sample_masked.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, C.POINTER(MaskBlend), i32, fp, fp, i32,
+                                         C.POINTER(C.c_int32), i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_ddpm_sample_masked.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, C.POINTER(MaskBlend), i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_randn.argtypes = [fp, C.c_size_t, C.c_uint64, C.c_uint64, vp]
     u8p = vp
     L.drm_refmap_workspace_bytes.argtypes = [C.c_int64, i32, C.c_float]

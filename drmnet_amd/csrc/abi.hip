@@ -361,6 +361,15 @@ int drm_drmnet_set_batch_parts(drm_drmnet* s, int parts) {
   });
 }
 
+int drm_drmnet_set_batch_part_min(drm_drmnet* s, int rows) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(s != nullptr, "drm_drmnet_set_batch_part_min: null handle");
+    DRM_REQUIRE(rows >= 1, "drm_drmnet_set_batch_part_min: at least one row per part");
+    s->s.part_min = rows;
+    return DRM_OK;
+  });
+}
+
 int drm_drmnet_step(drm_drmnet* s, float* Lr_k, const float* LrK, const int32_t* rows, int n_active, int step, const float* noise,
                     uint64_t seed, float* zk_out, float* zK_out, int32_t* converged_out, int B, int H, int W, void* workspace,
                     size_t workspace_bytes, void* stream) {
@@ -426,6 +435,41 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
     Arena ar;
     DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
     return ddpm_sample(&net->net, x, pred_x0, cond, coef, T_start, clip_denoised, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream));
+  });
+}
+
+static MaskBlend to_blend(const drm_mask_blend* b) {
+  MaskBlend m;
+  m.mask = b->mask; m.mask_channels = b->mask_channels; m.x0 = b->x0; m.qcoef = b->qcoef; m.qnoise = b->qnoise; m.when = b->when;
+  return m;
+}
+
+int drm_ddim_sample_masked(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
+                           const float* noise, uint64_t seed, const drm_mask_blend* blend, int log_every_t, float* log_x, float* log_pred_x0, int log_slots,
+                           int32_t* n_logged, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && x && cond && blend, "null argument");
+    DRM_REQUIRE(log_every_t <= 0 || (log_x && log_pred_x0 && log_slots > 0), "ddim intermediates: both log buffers and their slot count");
+    Arena ar;
+    DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
+    const MaskBlend mb = to_blend(blend);
+    int logged = 0;
+    const int rc = ddim_sample(&net->net, x, cond, timesteps, coef, S, num_steps, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream),
+                               log_every_t > 0 ? log_every_t : 0, log_every_t > 0 ? log_x : nullptr, log_every_t > 0 ? log_pred_x0 : nullptr, log_slots, &logged, &mb);
+    if (n_logged) *n_logged = logged;
+    return rc;
+  });
+}
+
+int drm_ddpm_sample_masked(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
+                           const float* noise, uint64_t seed, const drm_mask_blend* blend, int N, int H, int W, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  return guarded([&]() -> int {
+    DRM_REQUIRE(net && x && cond && blend, "null argument");
+    Arena ar;
+    DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
+    const MaskBlend mb = to_blend(blend);
+    return ddpm_sample(&net->net, x, pred_x0, cond, coef, T_start, clip_denoised, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream), &mb);
   });
 }
 

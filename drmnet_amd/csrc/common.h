@@ -181,18 +181,13 @@ int launch_linear(const float* in, const float* w, const float* b, float* out, i
 int launch_timestep_embedding(const int64_t* t, const float* tf, float* out, int N, int dim, hipStream_t s);
 int launch_encoder_head(const float* x, const float* scale, const float* shift, const float* w, const float* b, float* out, int N, int HW,
                         int C, int O, hipStream_t s);
-// the thin ends of a U-Net as kernels of their own (stemhead.hip): conv3x3(in_channels -> 128) on the NCHW boundary tensors (cat + row gather fused,
-// exact fp32 MFMA, fused output statistics) and GroupNorm -> SiLU -> conv3x3(C -> out_channels <= 4) with an NCHW store (exact fp32 FMAs)
+// the stem of a U-Net as a kernel of its own (stemhead.hip): conv3x3(in_channels -> 128) on the NCHW boundary tensors (cat + row gather fused,
+// fused output statistics)
 bool stem_direct_applicable(int Cin, int Cout);
 size_t stem_weight_floats();
 int launch_pack_stem_weight(const float* w, float* img, int Cout, int Cin, bool exact, hipStream_t s);  // exact: fp32 operands (PREC_FP32), else fp16 hi / lo
 int launch_stem_conv(const float* x, int Cx, const float* cond, int Cc, const int* rows, const float* wimg, const float* bias, float* out, double2* stat,
                      int N, int H, int W, int Cout, bool exact, hipStream_t s);
-bool head_direct_applicable(int C, int Cout);
-size_t head_weight_floats(int C);
-int launch_pack_head_weight(const float* w, float* img, int Cout, int C, hipStream_t s);
-int launch_head_conv(const float* x, const float* gn_scale, const float* gn_shift, const float* wimg, const float* bias, float* out, int N, int H, int W, int C,
-                     int Cout, hipStream_t s);
 int launch_nhwc_to_nchw(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
 int launch_nchw_to_nhwc(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
 

@@ -106,9 +106,9 @@ class UNet {
   size_t stem_s = 0;
   // packed-buffer offsets
   size_t te0_w = 0, te0_b = 0, te2_w = 0, te2_b = 0, stem_w = 0, stem_b = 0, embcat_w = 0, embcat_b = 0, on_w = 0, on_b = 0, oc_w = 0, oc_b = 0, oc_s = 0, scratch_off = 0;
-  // direct stem / head kernels (stemhead.hip): their own weight images, packed next to the generic ones; -1 = the generic conv path
-  long long stem_direct_w = -1, head_direct_w = -1;
-  int stem_param = -1, head_param = -1;  // indices of the source tensors in `params`
+  // direct stem kernel (stemhead.hip): its own weight image, packed next to the generic one; -1 = the generic conv path
+  long long stem_direct_w = -1;
+  int stem_param = -1;  // index of the source tensor in `params`
   size_t wbuf_floats = 0;
   // Packed weight images.  A network keeps up to DRM_WEIGHT_SETS of them side by side (set 0 = the live parameters, set 1 = the
   // EMA shadow the reference swaps in for sampling, ema.py:46-76): each is packed / pre-split ONCE and selected per forward, so

@@ -224,7 +224,6 @@ int UNet::build(const drm_unet_desc& d) {
   if (d.kind == 0) {
     DRM_REQUIRE(ch == mc, "UNetModel head expects model_channels inputs");
     oc_w = add_conv("out.2.weight", d.out_channels, mc, 3, out_cp, mc, false, &oc_s);
-    head_param = (int)params.size() - 1;
     oc_b = add_copy("out.2.bias", {d.out_channels}, out_cp);
   } else {
     oc_w = add_copy("out.3.weight", {d.out_channels, ch, 1, 1});
@@ -236,10 +235,6 @@ int UNet::build(const drm_unet_desc& d) {
   if (stem_direct_applicable(d.in_channels, mc)) {
     stem_direct_w = (long long)wbuf_floats;
     wbuf_floats += (stem_weight_floats() + 63) & ~size_t(63);
-  }
-  if (false && d.kind == 0 && head_direct_applicable(ch, d.out_channels)) {  // (head_conv_kernel measures 0.36 ms against 0.31 ms for the generic path: not yet)
-    head_direct_w = (long long)wbuf_floats;
-    wbuf_floats += (head_weight_floats(ch) + 63) & ~size_t(63);
   }
 #endif
   // fused embedding projection
@@ -274,7 +269,6 @@ int UNet::load(const float* const* ptrs, int count, hipStream_t s, int set) {
     }
   }
   if (stem_direct_w >= 0) DRM_TRY(launch_pack_stem_weight(ptrs[stem_param], wbuf + stem_direct_w, desc.model_channels, desc.in_channels, precision == PREC_FP32, s));
-  if (head_direct_w >= 0) DRM_TRY(launch_pack_head_weight(ptrs[head_param], wbuf + head_direct_w, desc.out_channels, final_ch, s));
   loaded[set] = true;
   loaded_precision[set] = precision;
   return DRM_OK;
@@ -704,9 +698,7 @@ int UNet::forward(const float* x, int Cx, const float* cond, int Cc, const int32
   DRM_TRY(arena_ok(c));
   DRM_TRY(gn_params(c, *h, nullptr, Wb + on_w, Wb + on_b, sc, sh, nullptr, nullptr));
   if (!c.dry()) {
-    if (desc.kind == 0 && head_direct_w >= 0) {
-      DRM_TRY(launch_head_conv(h->p, sc, sh, Wb + head_direct_w, Wb + oc_b, out, N, h->H, h->W, final_ch, desc.out_channels, s));
-    } else if (desc.kind == 0) {
+    if (desc.kind == 0) {
       ConvArgs a;
       a.src0 = h->p; a.C0 = final_ch; a.N = N; a.H = h->H; a.W = h->W;
       a.gn_scale = sc; a.gn_shift = sh; a.silu = 1;

@@ -200,6 +200,25 @@ __global__ void ddpm_update_kernel(float* __restrict__ x, float* __restrict__ pr
   if (pred_x0) pred_x0[i] = xr;
 }
 
+// Known-region blending of the samplers' `mask` / `x0` arguments (inpainting-style conditioning):
+//   img = q_sample(x0, t) * mask + (1 - mask) * img,   q_sample(x0, t) = sqrt(a_bar_t) x0 + sqrt(1 - a_bar_t) noise   (ddpm.py:1300-1302, :1052-1058)
+// applied BEFORE the step's network forward by DDIMSampler.ddim_sampling (at the step's own t, ddim.py:175-178) and by ObsNetDiffusion.p_sample_loop
+// (x0 itself at t == 0, else q_sample at t - 1, models/obsnet.py:545-547), and AFTER the update by LatentDiffusion.p_sample_loop (ddpm.py:1300-1302):
+// the host builds the (a, b) pair of every step, the kernel reads row `*counter` like the update kernels do, so graph replay applies unchanged.
+// mask: [N, mask_c, H, W] with mask_c == 1 (broadcast over the channels) or == C.  q-noise: [steps][n] injected, or Philox under its own key.
+__global__ void mask_blend_kernel(float* __restrict__ x, const float* __restrict__ x0, const float* __restrict__ mask, int mask_c, int C, size_t hw,
+                                  const float* __restrict__ qnoise, size_t n, const float* __restrict__ qtab, const int* __restrict__ counter, uint64_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = *counter;
+  const float a = qtab[2 * (size_t)j], b = qtab[2 * (size_t)j + 1];
+  float nz = 0.f;
+  if (b != 0.f) nz = qnoise ? qnoise[(size_t)j * n + i] : philox_normal1(seed ^ 0x9E3779B97F4A7C15ull, (uint64_t)(j + 1) * n + i);
+  const size_t p = i % hw, ch = (i / hw) % C, img = i / (hw * C);
+  const float m = mask[(img * mask_c + (mask_c == 1 ? 0 : ch)) * hw + p];
+  x[i] = (a * x0[i] + b * nz) * m + (1.0f - m) * x[i];
+}
+
 // ------------------------------------------------------------------------------------------------ DRMNet sampler
 
 DrmnetSampler::~DrmnetSampler() {
@@ -219,8 +238,6 @@ int DrmnetSampler::init(UNet* ill, UNet* ref, const float* const* zw, const drm_
   DRM_REQUIRE(c.z_dim >= 1 && c.z_dim <= 8 && ref->desc.out_channels == c.z_dim, "z_dim must match RefNet out_channels (<= 8)");
   DRM_REQUIRE(c.max_timesteps >= 1, "max_timesteps");
   illnet = ill; refnet = ref; cfg = c;
-  if (const char* e = getenv("DRM_BATCH_PARTS")) parts = std::max(1, std::min((int)PART_MAX, atoi(e)));  // (A/B runs; the API is drm_drmnet_set_batch_parts)
-  if (const char* e = getenv("DRM_BATCH_PART_MIN")) part_min = std::max(1, atoi(e));                        // (tests: small batches through the forked form)
   const int mc = ill->desc.model_channels, hd = mc / 2;
   const size_t sizes[6] = {(size_t)hd * c.z_dim, (size_t)hd, (size_t)hd * hd, (size_t)hd, (size_t)mc * hd, (size_t)mc};
   size_t total = 0;
@@ -254,6 +271,20 @@ static StepBuffers step_buffers(Arena& ar, int n, int zd, int mc, size_t chw) {
   return b;
 }
 
+// workspace bytes one batch part of nmax rows takes (the larger of the two networks' forwards; memoised: a dry walk of both networks)
+size_t DrmnetSampler::part_need(int nmax, int H, int W) const {
+  for (const auto& e : part_need_memo)
+    if (e.n == nmax && e.H == H && e.W == W) return e.bytes;
+  Arena p1; p1.dry = true;
+  Arena p2; p2.dry = true;
+  if (illnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nmax, H, W, p1, nullptr) != DRM_OK) return ~size_t(0);
+  if (refnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nmax, H, W, p2, nullptr) != DRM_OK) return ~size_t(0);
+  const size_t need = (std::max(p1.peak, p2.peak) + 255) & ~size_t(255);
+  if (part_need_memo.size() >= 64) part_need_memo.clear();
+  part_need_memo.push_back({nmax, H, W, need});
+  return need;
+}
+
 size_t DrmnetSampler::workspace_bytes(int N, int H, int W) const {
   Arena ar;
   ar.dry = true;
@@ -267,12 +298,9 @@ size_t DrmnetSampler::workspace_bytes(int N, int H, int W) const {
   if (refnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a2, nullptr) != DRM_OK) return 0;
   size_t need = std::max(a1.peak, a2.peak);
   for (int np = 2; np <= std::min(std::min(parts, (int)PART_MAX), N / std::max(part_min, 1)); ++np) {  // the batch parts' workspace slices (step)
-    const int nmax = (N + np - 1) / np;
-    Arena p1; p1.dry = true;
-    Arena p2; p2.dry = true;
-    if (illnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nmax, H, W, p1, nullptr) != DRM_OK) return 0;
-    if (refnet->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, nmax, H, W, p2, nullptr) != DRM_OK) return 0;
-    need = std::max(need, (size_t)np * ((std::max(p1.peak, p2.peak) + 511) & ~size_t(255)));
+    const size_t pn = part_need((N + np - 1) / np, H, W);
+    if (pn == ~size_t(0)) return 0;
+    need = std::max(need, (size_t)np * (pn + 256));
   }
   return base + need + 512;
 }
@@ -287,7 +315,15 @@ int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int 
   if (ar.failed) { set_error("drmnet step: workspace too small"); return DRM_ERR_WORKSPACE; }
   // (not under the launch profiler: it brackets every launch with events on the launch stream, and a bracket on one part's stream would include
   //  the other part's kernels -- the profiled pass runs the whole batch on the caller's stream)
-  const int np = prof_enabled() ? 1 : std::min(std::min(parts, (int)PART_MAX), n / std::max(part_min, 1));
+  int np = prof_enabled() ? 1 : std::min(std::min(parts, (int)PART_MAX), n / std::max(part_min, 1));
+  // the parts' workspace slices: 256-byte aligned starts behind the step's own buffers, each as large as the largest part needs.  A workspace sized
+  // before drm_drmnet_set_batch_parts raised the part count (or by hand) may not hold them: then the step runs on the caller's stream alone.
+  const size_t a0 = (ar.off + 255) & ~size_t(255);
+  size_t room = 0;
+  if (np >= 2 && !ar.dry) {
+    room = a0 < ar.cap ? ((ar.cap - a0) / np) & ~size_t(255) : 0;
+    if (room < part_need((n + np - 1) / np, H, W)) np = 1;
+  }
   if (np < 2 || ar.dry) {
     DRM_TRY(step_rows(Lr_k, LrK, rows, 0, n, i, noise, seed, b, 0, B, H, W, ar, s));
   } else {
@@ -297,13 +333,12 @@ int DrmnetSampler::step(float* Lr_k, const float* LrK, const int32_t* rows, int 
       if (!part_stream[k]) DRM_HIP_CHECK(hipStreamCreateWithFlags(&part_stream[k], hipStreamNonBlocking));
       if (!part_done[k]) DRM_HIP_CHECK(hipEventCreateWithFlags(&part_done[k], hipEventDisableTiming));
     }
-    const size_t room = ((ar.cap - ar.off) / np) & ~size_t(255);
     DRM_HIP_CHECK(hipEventRecord(part_fork, s));
     int rc = DRM_OK;
     for (int k = 0; k < np && rc == DRM_OK; ++k) {
       const int j0 = (int)((long long)n * k / np), j1 = (int)((long long)n * (k + 1) / np);
       Arena sub;
-      sub.base = ar.base + ((ar.off + 255) & ~size_t(255)) + (size_t)k * room;
+      sub.base = ar.base + a0 + (size_t)k * room;
       sub.cap = room;
       hipStream_t ps = part_stream[k];
       DRM_HIP_CHECK(hipStreamWaitEvent(ps, part_fork, 0));
@@ -409,7 +444,8 @@ size_t sampler_workspace_bytes(UNet* net, int N, int H, int W) {
   if (net->forward(nullptr, 3, nullptr, 3, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, a, nullptr) != DRM_OK) return 0;
   const size_t chw = (size_t)net->desc.out_channels * H * W;
   // U-Net arena + eps [N,C,H,W] + timesteps [N] + the per-step scalar table (<= 4096 steps) and its counter
-  return a.peak + ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + ((size_t)MAX_TABLE_STEPS * STEP_ROW * sizeof(float) + 256) + 1024;
+  // (+ the mask-blend (a, b) pair per step, same bound)
+  return a.peak + ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + ((size_t)MAX_TABLE_STEPS * (STEP_ROW + 2) * sizeof(float) + 512) + 1024;
 }
 
 // Runs `steps` identical-launch steps: the first eagerly (it also sizes caches and sets per-kernel attributes), the second under
@@ -527,9 +563,18 @@ static int upload_step_table(const std::vector<float>& rows, float* tab, int* co
   return DRM_OK;
 }
 
+// uploads the blend's per-step (a, b) pairs behind the step table (same stream, pageable source: hipMemcpyAsync returns after staging it)
+static int upload_blend_table(const MaskBlend* blend, int steps, float* qtab, hipStream_t s) {
+  DRM_REQUIRE(blend->mask && blend->x0 && blend->qcoef, "mask blending needs mask, x0 and the per-step q_sample coefficients");
+  DRM_REQUIRE(blend->mask_channels >= 1 && (blend->when == 0 || blend->when == 1), "mask blending: mask_channels >= 1, when = 0 (before the forward) or 1 (after the update)");
+  DRM_HIP_CHECK(hipMemcpyAsync(qtab, blend->qcoef, (size_t)steps * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+  DRM_HIP_CHECK(hipStreamSynchronize(s));  // (the caller's table may be freed when the call returns under graph replay / eager alike)
+  return DRM_OK;
+}
+
 int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
                 uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller, int log_every_t, float* log_x, float* log_pred, int log_slots,
-                int* n_logged) {
+                int* n_logged, const MaskBlend* blend) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddim needs a UNetModel");
   DRM_REQUIRE(S >= 1 && timesteps && coef, "ddim schedule");
   DRM_REQUIRE(S <= MAX_TABLE_STEPS, "ddim: at most " + std::to_string(MAX_TABLE_STEPS) + " steps (the workspace budgets the step table for that many)");
@@ -542,7 +587,9 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
   float* tf = ar.alloc<float>((size_t)N);
   float* tab = ar.alloc<float>((size_t)steps * STEP_ROW);
   int* counter = ar.alloc<int>(1);
+  float* qtab = blend ? ar.alloc<float>((size_t)steps * 2) : nullptr;
   if (ar.failed) { set_error("ddim: workspace too small"); return DRM_ERR_WORKSPACE; }
+  DRM_REQUIRE(!blend || blend->mask_channels == 1 || blend->mask_channels == Cx, "mask blending: the mask has 1 or out_channels channels");
   std::vector<float> rows((size_t)steps * STEP_ROW, 0.f);
   int logged = 0;
   DRM_REQUIRE(!log_x || log_pred, "ddim: the intermediates log needs both buffers");
@@ -558,14 +605,24 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
   }
   if (n_logged) *n_logged = logged;
   DRM_TRY(upload_step_table(rows, tab, counter, s));
+  if (blend) DRM_TRY(upload_blend_table(blend, steps, qtab, s));
   const size_t mark = ar.mark();
+  const size_t hw = (size_t)H * W;
+  auto blend_now = [&]() -> int {
+    hipLaunchKernelGGL(mask_blend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, blend->x0, blend->mask, blend->mask_channels, Cx, hw, blend->qnoise, n,
+                       qtab, counter, seed);
+    DRM_HIP_CHECK(hipGetLastError());
+    return DRM_OK;
+  };
   return run_steps(steps, s, [&]() -> int {
     hipLaunchKernelGGL(step_begin_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tab, counter, tf, N);
     DRM_HIP_CHECK(hipGetLastError());
+    if (blend && blend->when == 0) DRM_TRY(blend_now());
     ar.release(mark);
     DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
     hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, e, noise, n, tab, counter, seed, log_x, log_pred);
     DRM_HIP_CHECK(hipGetLastError());
+    if (blend && blend->when == 1) DRM_TRY(blend_now());
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);
     DRM_HIP_CHECK(hipGetLastError());
     return DRM_OK;
@@ -573,7 +630,7 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
 }
 
 int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip, const float* noise,
-                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller) {
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller, const MaskBlend* blend) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddpm needs a UNetModel");
   DRM_REQUIRE(T_start >= 1 && coef, "ddpm schedule");
   DRM_REQUIRE(T_start <= MAX_TABLE_STEPS, "ddpm: at most " + std::to_string(MAX_TABLE_STEPS) + " steps (the workspace budgets the step table for that many)");
@@ -585,7 +642,9 @@ int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const fl
   float* tf = ar.alloc<float>((size_t)N);
   float* tab = ar.alloc<float>((size_t)T_start * STEP_ROW);
   int* counter = ar.alloc<int>(1);
+  float* qtab = blend ? ar.alloc<float>((size_t)T_start * 2) : nullptr;
   if (ar.failed) { set_error("ddpm: workspace too small"); return DRM_ERR_WORKSPACE; }
+  DRM_REQUIRE(!blend || blend->mask_channels == 1 || blend->mask_channels == Cx, "mask blending: the mask has 1 or out_channels channels");
   std::vector<float> rows((size_t)T_start * STEP_ROW, 0.f);
   for (int j = 0; j < T_start; ++j) {
     const int t = T_start - 1 - j;
@@ -594,14 +653,24 @@ int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const fl
     rows[(size_t)j * STEP_ROW + 6] = t != 0 ? 1.f : 0.f;  // no noise at t == 0 (ddpm.py:1161)
   }
   DRM_TRY(upload_step_table(rows, tab, counter, s));
+  if (blend) DRM_TRY(upload_blend_table(blend, T_start, qtab, s));
   const size_t mark = ar.mark();
+  const size_t hw = (size_t)H * W;
+  auto blend_now = [&]() -> int {
+    hipLaunchKernelGGL(mask_blend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, blend->x0, blend->mask, blend->mask_channels, Cx, hw, blend->qnoise, n,
+                       qtab, counter, seed);
+    DRM_HIP_CHECK(hipGetLastError());
+    return DRM_OK;
+  };
   return run_steps(T_start, s, [&]() -> int {
     hipLaunchKernelGGL(step_begin_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tab, counter, tf, N);
     DRM_HIP_CHECK(hipGetLastError());
+    if (blend && blend->when == 0) DRM_TRY(blend_now());
     ar.release(mark);
     DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
     hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, pred_x0, e, noise, n, tab, counter, clip, seed);
     DRM_HIP_CHECK(hipGetLastError());
+    if (blend && blend->when == 1) DRM_TRY(blend_now());
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);
     DRM_HIP_CHECK(hipGetLastError());
     return DRM_OK;

@@ -1,16 +1,16 @@
-// The two thin ends of a U-Net, as kernels of their own ("Stem (Cin = 6) and head (Cout = 3) get thin special cases").
+// The stem of a U-Net as a kernel of its own ("Stem (Cin = 6) and head (Cout = 3) get thin special cases").
 //
 //   stem_conv_kernel  input_blocks.0.0 = conv3x3(in_channels -> model_channels) on the raw network input (openaimodel.py:534, :757).  Through the
 //                     generic pipeline kernel the 6 input channels were padded to one 32-channel chunk (K = 288 for 54 real taps x channels) behind
 //                     a pack launch and a range-guard launch: 0.27 + 0.05 ms at batch 32 for a layer whose floor is its 537 MB output write.  Here:
 //                     one launch reads x and cond in their NCHW boundary layout (cat([x, cond], 1) of DiffusionWrapper, ddpm.py:1527-1529, and the
 //                     DRMNet active-row gather, drmnet.py:810-813, fused as before), builds the im2col rows (K = 9 * Cin, tap-major) in LDS and runs
-//                     EXACT fp32 products on v_mfma_f32_32x32x2_f32 in every precision mode (the layer is 0.05 % of a step's FLOPs: no split
-//                     arithmetic, no range guard, no mode-dependent weight image), bias, NHWC store and the fused GroupNorm statistics of the output.
-//   head_conv_kernel  out = GroupNorm32 -> SiLU -> conv3x3(model_channels -> out_channels) (openaimodel.py:703-707, :768), NCHW store.  Through the
-//                     pipeline kernel the 3 output channels were padded to 32 (23 TF): here every lane owns one pixel and keeps its out_channels
-//                     sums in registers -- exact fp32 FMAs on the vector unit, the normalised + activated halo tile staged once per 32-channel
-//                     chunk in LDS, weights broadcast from scalar registers; bound by the 537 MB read of its input.
+//                     its products on the matrix pipe -- EXACT fp32 (v_mfma_f32_32x32x2_f32, 28 MFMAs of 64 cycles per block) in the fp32 mode; in
+//                     every other mode the fp16 hi / lo split (12 v_mfma_f32_32x32x16_f16 per block) behind a per-TILE power of two taken from the
+//                     tile's max |v| (exact, undone in the epilogue; a tile holding NaN / Inf goes through unclamped so the poison propagates) --
+//                     then bias, NHWC store and the fused GroupNorm statistics of the output.
+// (The head keeps the generic pipeline kernel: a kernel of its own -- one pixel per lane, exact fp32 FMAs -- measured 0.36 ms against 0.31 ms and
+//  lives in tools/experiments/head_conv_kernel_r5.hip.txt, not in the library.)
 #include <algorithm>
 #include <atomic>
 
@@ -162,12 +162,15 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
       }
       const float sc = ldexpf(1.0f, k);
       t_inv = ldexpf(1.0f, -k);
+      const bool finite_tile = bound < INFINITY;
       ShF4H8 hi[4], lo[4];
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
         _Float16 hh = (_Float16)0.f, ll = (_Float16)0.f;
         if (j < C::KH) {
-          const float v = __builtin_amdgcn_fmed3f(av[j] * sc, -65504.0f, 65504.0f);
+          // (a tile that holds a NaN / Inf pixel has no finite bound: its values go through unclamped, so the poison propagates into the outputs of
+          //  that tile as it does through F.conv2d -- a downstream isfinite() guard sees it; finite tiles are untouched: ADVICE r5)
+          const float v = finite_tile ? __builtin_amdgcn_fmed3f(av[j] * sc, -65504.0f, 65504.0f) : av[j];
           hh = (_Float16)v;
           ll = (_Float16)(v - (float)hh);
         }
@@ -382,8 +385,10 @@ int launch_stem_conv(const float* x, int Cx, const float* cond, int Cc, const in
   const int grid = (int)std::min<long long>(tiles, 2ll * di->cus);
   prof_tag(N, H, W, Cin, Cout);
   ProfScope ps(PROF_CONV3, 2.0 * N * H * W * 9.0 * Cin * Cout, 4.0 * ((double)N * H * W * (Cin + Cout) + 9.0 * Cin * Cout), s);
-  auto go = [&](auto kern) -> int {
-    static std::atomic<uint64_t> attr_mask{0};
+  // one opt-in mask PER kernel variant (all four share a function-pointer type, so a static inside the generic lambda would be shared: ADVICE r5)
+  static std::atomic<uint64_t> attr_masks[4];
+  auto go = [&](auto kern, int variant) -> int {
+    std::atomic<uint64_t>& attr_mask = attr_masks[variant];
     if (!(attr_mask.load(std::memory_order_acquire) >> di->ordinal & 1)) {
       DRM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_mask.fetch_or(uint64_t(1) << di->ordinal, std::memory_order_release);
@@ -392,125 +397,8 @@ int launch_stem_conv(const float* x, int Cx, const float* cond, int Cc, const in
     DRM_HIP_CHECK(hipGetLastError());
     return DRM_OK;
   };
-  if (Cin == 4) return exact ? go(stem_conv_kernel<4, true>) : go(stem_conv_kernel<4, false>);
-  return exact ? go(stem_conv_kernel<6, true>) : go(stem_conv_kernel<6, false>);
-}
-
-// ---------------------------------------------------------------------------------------------- head
-namespace {
-
-constexpr int HEAD_T = 16;                  // 16 x 16 pixels per workgroup, one pixel per lane
-constexpr int HEAD_HT = HEAD_T + 2;         // halo tile edge
-constexpr int HEAD_PS = 36;                 // floats per staged pixel (32 channels + 4: consecutive pixels land 144 bytes apart = 16 distinct 16-byte slots per 16 lanes)
-constexpr int HEAD_WF = 9 * 32 * 4;         // floats of one chunk's weights: [tap][channel][4] (out_channels <= 4, zero padded)
-
-__device__ __forceinline__ float head_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-
-template <int COUT>
-__global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ gn_scale, const float* __restrict__ gn_shift,
-                                                        const float* __restrict__ wimg /* [C / 32][9][32][4] */, const float* __restrict__ bias,
-                                                        float* __restrict__ out, int N, int H, int W, int C) {
-  __shared__ float4 tile4[HEAD_HT * HEAD_HT * HEAD_PS / 4];
-  float* tile = reinterpret_cast<float*>(tile4);
-  const int tid = threadIdx.x;
-  const int tiles_x = (W + HEAD_T - 1) / HEAD_T, tiles_y = (H + HEAD_T - 1) / HEAD_T;
-  const int n = blockIdx.x / (tiles_x * tiles_y), ti = blockIdx.x % (tiles_x * tiles_y);
-  const int ty0 = (ti / tiles_x) * HEAD_T, tx0 = (ti % tiles_x) * HEAD_T;
-  const int ly = tid >> 4, lx = tid & 15;
-  const int sq = tid & 7;  // the channel quad this thread stages (fixed: 256 % 8 == 0)
-  float acc[COUT];
-#pragma unroll
-  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
-  constexpr int ITEMS = HEAD_HT * HEAD_HT * 8, ITERS = (ITEMS + 255) / 256;
-  for (int c0 = 0; c0 < C; c0 += 32) {
-    const float4 sc = *reinterpret_cast<const float4*>(gn_scale + (size_t)n * C + c0 + 4 * sq);
-    const float4 sh = *reinterpret_cast<const float4*>(gn_shift + (size_t)n * C + c0 + 4 * sq);
-    float4 raw[ITERS];
-    unsigned inside = 0;  // bit it: the staged pixel lies inside the map (conv zero padding applies to the ACTIVATED map: zero after the SiLU)
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int idx = it * 256 + tid, hp = idx >> 3;
-      const int y = ty0 + hp / HEAD_HT - 1, xx = tx0 + hp % HEAD_HT - 1;
-      if (idx < ITEMS && y >= 0 && y < H && xx >= 0 && xx < W) inside |= 1u << it;
-      const int yc = min(max(y, 0), H - 1), xc = min(max(xx, 0), W - 1);
-      raw[it] = *reinterpret_cast<const float4*>(x + (((size_t)n * H + yc) * W + xc) * C + c0 + 4 * sq);
-    }
-    if (c0) __syncthreads();  // the previous chunk's reads are done
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int idx = it * 256 + tid, hp = idx >> 3;
-      if (idx < ITEMS) {
-        float4 v;
-        v.x = head_silu(raw[it].x * sc.x + sh.x);
-        v.y = head_silu(raw[it].y * sc.y + sh.y);
-        v.z = head_silu(raw[it].z * sc.z + sh.z);
-        v.w = head_silu(raw[it].w * sc.w + sh.w);
-        if (!((inside >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(tile + hp * HEAD_PS + 4 * sq) = v;
-      }
-    }
-    __syncthreads();
-    const float* wc = wimg + (size_t)(c0 / 32) * HEAD_WF;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const float* tp = tile + ((ly + tap / 3) * HEAD_HT + lx + tap % 3) * HEAD_PS;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 a = *reinterpret_cast<const float4*>(tp + 4 * q);
-        const float* w = wc + (tap * 32 + 4 * q) * 4;  // wave-uniform: scalar loads
-#pragma unroll
-        for (int o = 0; o < COUT; ++o) {
-          acc[o] = fmaf(a.x, w[o], acc[o]);
-          acc[o] = fmaf(a.y, w[4 + o], acc[o]);
-          acc[o] = fmaf(a.z, w[8 + o], acc[o]);
-          acc[o] = fmaf(a.w, w[12 + o], acc[o]);
-        }
-      }
-    }
-  }
-  const int y = ty0 + ly, xx = tx0 + lx;
-  if (y < H && xx < W) {
-#pragma unroll
-    for (int o = 0; o < COUT; ++o) out[(((size_t)n * COUT + o) * H + y) * W + xx] = acc[o] + bias[o];
-  }
-}
-
-// PyTorch [Cout][C][3][3] -> [C / 32][tap][32][4]
-__global__ void pack_head_weight_kernel(const float* __restrict__ w, float* __restrict__ img, int Cout, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (C / 32) * HEAD_WF) return;
-  const int o = i & 3, ch = (i >> 2) & 31, tap = (i >> 7) % 9, chunk = i / HEAD_WF;
-  img[i] = o < Cout ? w[((size_t)o * C + chunk * 32 + ch) * 9 + tap] : 0.f;
-}
-
-}  // namespace
-
-bool head_direct_applicable(int C, int Cout) { return C % 32 == 0 && Cout >= 1 && Cout <= 4; }
-size_t head_weight_floats(int C) { return (size_t)(C / 32) * HEAD_WF; }
-
-int launch_pack_head_weight(const float* w, float* img, int Cout, int C, hipStream_t s) {
-  DRM_REQUIRE(head_direct_applicable(C, Cout), "head weight image: unsupported channel counts");
-  const int n = (C / 32) * HEAD_WF;
-  hipLaunchKernelGGL(pack_head_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, img, Cout, C);
-  DRM_HIP_CHECK(hipGetLastError());
-  return DRM_OK;
-}
-
-int launch_head_conv(const float* x, const float* gn_scale, const float* gn_shift, const float* wimg, const float* bias, float* out, int N, int H, int W, int C,
-                     int Cout, hipStream_t s) {
-  DRM_REQUIRE(head_direct_applicable(C, Cout) && gn_scale && gn_shift, "head kernel: unsupported channel counts");
-  const long long tiles = (long long)N * ((H + HEAD_T - 1) / HEAD_T) * ((W + HEAD_T - 1) / HEAD_T);
-  DRM_REQUIRE(tiles > 0 && tiles < (1ll << 31), "head grid size");
-  prof_tag(N, H, W, C, Cout);
-  ProfScope ps(PROF_CONV3, 2.0 * N * H * W * 9.0 * C * Cout, 4.0 * ((double)N * H * W * (C + Cout) + 9.0 * C * Cout), s);
-  switch (Cout) {
-    case 1: hipLaunchKernelGGL(head_conv_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, s, x, gn_scale, gn_shift, wimg, bias, out, N, H, W, C); break;
-    case 2: hipLaunchKernelGGL(head_conv_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, s, x, gn_scale, gn_shift, wimg, bias, out, N, H, W, C); break;
-    case 3: hipLaunchKernelGGL(head_conv_kernel<3>, dim3((unsigned)tiles), dim3(256), 0, s, x, gn_scale, gn_shift, wimg, bias, out, N, H, W, C); break;
-    default: hipLaunchKernelGGL(head_conv_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, s, x, gn_scale, gn_shift, wimg, bias, out, N, H, W, C); break;
-  }
-  DRM_HIP_CHECK(hipGetLastError());
-  return DRM_OK;
+  if (Cin == 4) return exact ? go(stem_conv_kernel<4, true>, 0) : go(stem_conv_kernel<4, false>, 1);
+  return exact ? go(stem_conv_kernel<6, true>, 2) : go(stem_conv_kernel<6, false>, 3);
 }
 
 }  // namespace drm

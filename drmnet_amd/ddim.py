@@ -81,20 +81,34 @@ class DDIMSampler(object):
         if conditioning is not None and not isinstance(conditioning, dict):
             if conditioning.shape[0] != batch_size:
                 print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
-        if any(v is not None for v in (callback, img_callback, mask, x0, score_corrector, unconditional_conditioning)) or quantize_x0:
-            raise NotImplementedError("callbacks / mask / guidance / quantize are not on the shipped path")
-        if temperature != 1.0 or noise_dropout != 0.0 or unconditional_guidance_scale != 1.0:
-            raise NotImplementedError("temperature / noise_dropout / guidance are not on the shipped path")
+        if any(v is not None for v in (callback, img_callback, score_corrector, unconditional_conditioning)) or quantize_x0:
+            raise NotImplementedError("callbacks / score corrector / classifier-free guidance / quantize are not on the shipped path")
+        if noise_dropout != 0.0 or unconditional_guidance_scale != 1.0:
+            raise NotImplementedError("noise_dropout / guidance are not on the shipped path")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         size = (batch_size, *shape)
-        return self.ddim_sampling(conditioning, size, x_T=x_T, log_every_t=log_every_t, verbose=verbose, noise=noise, seed=seed, num_steps=num_steps)
+        return self.ddim_sampling(conditioning, size, x_T=x_T, log_every_t=log_every_t, verbose=verbose, noise=noise, seed=seed, num_steps=num_steps,
+                                  mask=mask, x0=x0, temperature=temperature, mask_noise=kwargs.get("mask_noise"))
 
     @torch.no_grad()
-    def ddim_sampling(self, cond, shape, x_T=None, log_every_t=100, verbose=True, noise=None, seed=None, num_steps=None, **unused):
+    def ddim_sampling(self, cond, shape, x_T=None, log_every_t=100, verbose=True, noise=None, seed=None, num_steps=None, mask=None, x0=None,
+                      temperature=1.0, mask_noise=None, noise_dropout=0.0, callback=None, img_callback=None, quantize_denoised=False, score_corrector=None,
+                      corrector_kwargs=None, unconditional_guidance_scale=1.0, unconditional_conditioning=None, ddim_use_original_steps=False,
+                      timesteps=None):
         """ddim.py:128-204 -> (final x, intermediates).  ``intermediates`` is the reference's record (ddim.py:171-204): "x_inter" and "pred_x0" start
         with x_T and receive (img, pred_x0) after the step of ``index`` whenever index % log_every_t == 0 or at the first step -- written by the
-        update kernel of the steps the device table marks (csrc/samplers.hip), so the chain stays one device loop."""
+        update kernel of the steps the device table marks (csrc/samplers.hip), so the chain stays one device loop.
+        ``mask`` / ``x0`` (ddim.py:175-178): before every step img = q_sample(x0, t) * mask + (1 - mask) * img, on the device (mask_blend_kernel;
+        ``mask_noise`` [steps,N,C,H,W] injects q_sample's draws, else Philox).  ``temperature`` (ddim.py:255) scales the step noise: the sigma column
+        of the coefficient table.  Guidance, score correctors, noise_dropout, callbacks and quantisation stay rejected."""
         from . import ops
+
+        if any(v is not None for v in (callback, img_callback, score_corrector, unconditional_conditioning, timesteps)) or quantize_denoised or ddim_use_original_steps:
+            raise NotImplementedError("callbacks / score corrector / classifier-free guidance / quantize / original-step schedules are not on the shipped path")
+        if noise_dropout != 0.0 or unconditional_guidance_scale != 1.0:
+            raise NotImplementedError("noise_dropout / guidance are not on the shipped path")
+        if (mask is None) != (x0 is None):
+            raise ValueError("mask and x0 go together (ddim.py:176)")
 
         dev = self.model.betas.device
         if seed is None:
@@ -107,20 +121,41 @@ class DDIMSampler(object):
         unet = self.model.model.diffusion_model
         h = unet.engine_handle()
         if getattr(self.model, "_auto_chain", None) is not None:  # auto mode: the model's chain probe may move the network to f16x3 for these weights
-            self.model._auto_chain_probe()
+            self.model._auto_chain_probe(c)  # (on rows of the caller's conditioning, once per weight signature)
             h = unet.engine_handle()
         L = _lib.lib()
         n, _, hh, ww = shape
         ws = self._ws.get(int(L.drm_sampler_workspace_bytes(h, n, hh, ww)), dev)
         ts = np.ascontiguousarray(np.asarray(self.ddim_timesteps, dtype=np.int64))
         coef = np.ascontiguousarray(self.ddim_coef)
+        if temperature != 1.0:  # noise = sigma_t * randn * temperature (ddim.py:255); dir_xt keeps the un-scaled sigma (its own column)
+            coef = coef.copy()
+            coef[:, 4] = (torch.from_numpy(coef[:, 4]) * float(temperature)).numpy()
         S = len(ts)
         steps = S if not num_steps else min(int(num_steps), S)
+        blend = keep = None
+        if mask is not None:
+            # q_sample(x0, ts) at the step's own t (ddpm.py:1052-1058: sqrt_alphas_cumprod[t] x0 + sqrt_one_minus_alphas_cumprod[t] noise)
+            sa = self.model.sqrt_alphas_cumprod.detach().cpu().float().numpy()
+            s1 = self.model.sqrt_one_minus_alphas_cumprod.detach().cpu().float().numpy()
+            q = np.array([[sa[int(ts[S - 1 - j])], s1[int(ts[S - 1 - j])]] for j in range(steps)], dtype=np.float32)
+            blend, keep = _lib.make_mask_blend(mask, x0, q, mask_noise, 0, tuple(img.shape))
         log_every_t = int(log_every_t) if log_every_t else 0
         slots = sum(1 for j in range(steps) if log_every_t > 0 and ((S - 1 - j) % log_every_t == 0 or j == 0))
         inter = {"x_inter": [x_start], "pred_x0": [x_start]}
         with torch.cuda.device(dev):
-            if slots == 0:
+            if blend is not None:
+                log_x = torch.empty((max(slots, 1),) + tuple(img.shape), dtype=torch.float32, device=dev)
+                log_p = torch.empty_like(log_x)
+                n_logged = C.c_int32(0)
+                _lib.check(L.drm_ddim_sample_masked(h, img.data_ptr(), c.data_ptr(), ts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                    coef.ctypes.data_as(C.POINTER(C.c_float)), S, int(num_steps or 0), _lib.ptr(noise), seed, C.byref(blend),
+                                                    log_every_t if slots else 0, log_x.data_ptr(), log_p.data_ptr(), slots, C.byref(n_logged), n, hh, ww,
+                                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+                torch.cuda.current_stream(dev).synchronize()  # (the blend's tensors stay alive until the chain has run)
+                inter["x_inter"] += [log_x[k] for k in range(n_logged.value)]
+                inter["pred_x0"] += [log_p[k] for k in range(n_logged.value)]
+            elif slots == 0:
                 _lib.check(L.drm_ddim_sample(h, img.data_ptr(), c.data_ptr(), ts.ctypes.data_as(C.POINTER(C.c_int64)),
                                              coef.ctypes.data_as(C.POINTER(C.c_float)), S, int(num_steps or 0), _lib.ptr(noise), seed, n, hh, ww,
                                              ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))

@@ -196,14 +196,17 @@ class DRMNet(nn.Module):
     def p_sample(self, Lr_k, illnet_cond, refnet_cond, reversed_k, return_model_out=False):
         raise NotImplementedError("")  # the reference leaves this unimplemented too (drmnet.py:772-780)
 
-    def set_precision(self, precision: str) -> "DRMNet":
+    def set_precision(self, precision: str, probe: Optional[torch.Tensor] = None) -> "DRMNet":
         """Conv arithmetic of both networks: "fp32" (exact fp32 MFMA), "f16x3" (split fp16, fp32-accurate, ~2.5x faster), "f16mx" (f16x3 with
         fp8 cross terms on the 3x3 convs: ~3e-5 per network, ~3x faster), "auto" (f16mx per network only where a probe forward on the loaded
         weights agrees with f16x3 to 5e-5, else f16x3: unet.set_precision_auto), "f16" / "bf16" (reduced precision)."""
         self.illnet_model.diffusion_model.set_precision(precision)
         self.refnet_model.diffusion_model.set_precision(precision)
         # "auto": besides the per-network probes (unet.py), the CHAIN is measured before f16mx is kept -- see _auto_chain_probe
-        self._auto_chain = {"tolerance": self.AUTO_CHAIN_TOLERANCE, "steps": self.AUTO_CHAIN_STEPS, "done": {}, "busy": False, "report": None} if precision == "auto" else None
+        # ``probe`` [n,3,H,W]: refmaps of the CALLER to measure the chain on (the first and the middle row are used) instead of the seeded synthetic
+        # pair; without it the first batch p_sample_loop sees is handed to the probe (once per weight signature)
+        self._auto_chain = {"tolerance": self.AUTO_CHAIN_TOLERANCE, "steps": self.AUTO_CHAIN_STEPS, "done": {}, "busy": False, "report": None,
+                            "probe": None if probe is None else _lib.require_gpu_tensor(probe, "probe").detach()} if precision == "auto" else None
         return self
 
     AUTO_CHAIN_TOLERANCE = 5e-5  # half the 1e-4 contract, like the per-network probe
@@ -215,32 +218,51 @@ class DRMNet(nn.Module):
         ac = getattr(self, "_auto_chain", None)
         return None if ac is None else ac["report"]
 
-    def calibrate_precision(self) -> Optional[dict]:
-        """Auto mode: runs the per-network probes and the chain probe now (weights on a GPU) and returns the chain report."""
+    def calibrate_precision(self, probe: Optional[torch.Tensor] = None) -> Optional[dict]:
+        """Auto mode: runs the per-network probes and the chain probe now (weights on a GPU) and returns the chain report.  ``probe``: refmaps of the
+        caller to run the chain on (re-measured for these rows even if a probe of these weights is on record)."""
+        ac = getattr(self, "_auto_chain", None)
+        if ac is not None and probe is not None:
+            ac["probe"] = _lib.require_gpu_tensor(probe, "probe").detach()
+            ac["done"] = {k: v for k, v in ac["done"].items() if k[-1] != "data"}
         self._engine()
         return self.auto_chain_report
 
     @torch.no_grad()
-    def _auto_chain_probe(self, which: str) -> None:
+    def _auto_chain_probe(self, which: str, data: Optional[torch.Tensor] = None) -> None:
         """A per-network probe compares ONE forward; the sampler applies ~100 of them to its own output.  So where the networks settled on f16mx, eight
-        reverse steps (RefNet -> schedule -> z-MLP -> IllNet -> update, Philox noise from a fixed key, every row active: drm_drmnet_step) are run from
-        two seeded refmaps at 128x128 in the chosen modes and in f16x3; f16mx is kept only if every row of the final state agrees to `tolerance`,
-        otherwise BOTH networks run in f16x3 for these weights."""
+        reverse steps (RefNet -> schedule -> z-MLP -> IllNet -> update, Philox noise from a fixed key, every row active: drm_drmnet_step) are run in
+        the chosen modes and in f16x3; f16mx is kept only if every row of the final state agrees to `tolerance`, otherwise BOTH networks run in f16x3
+        for these weights.  The rows: the CALLER's refmaps when there are any -- ``data`` (the batch p_sample_loop was called with, or the ``probe`` of
+        set_precision / calibrate_precision; first and middle row, at their own size), once per weight signature -- else two seeded synthetic refmaps at
+        128x128 (calibrate_precision() before any data exists)."""
         from . import synth
 
         ac = self._auto_chain
         ill, ref = self.illnet_model.diffusion_model, self.refnet_model.diffusion_model
-        if ill.auto_report is None or ref.auto_report is None or "f16mx" not in (ill.precision, ref.precision):
+        if ill.auto_report is None or ref.auto_report is None:
             return
-        key = (which, ill.__dict__["_auto"]["sig"], ref.__dict__["_auto"]["sig"])
+        if data is None:
+            data = ac.get("probe")
+        sigs = (which, ill.__dict__["_auto"]["sig"], ref.__dict__["_auto"]["sig"])
+        key = sigs + ("data" if data is not None else "synth",)
+        if key not in ac["done"] and data is None and sigs + ("data",) in ac["done"]:
+            key = sigs + ("data",)  # (measured on the caller's rows before: that record stands)
         if key in ac["done"]:
             ac["report"] = ac["done"][key]
+            return
+        if "f16mx" not in (ill.precision, ref.precision):
             return
         ac["busy"] = True
         try:
             dev = next(ill.parameters()).device
-            B, H, W = 2, 128, 128
-            x = synth.synth_refmaps(B, H, W, 4321).to(dev)
+            if data is not None:
+                x = data[[0, data.shape[0] // 2]] if data.shape[0] > 1 else data[:1]
+                x = x.detach().to(dev, torch.float32).contiguous()
+                B, H, W = x.shape[0], x.shape[2], x.shape[3]
+            else:
+                B, H, W = 2, 128, 128
+                x = synth.synth_refmaps(B, H, W, 4321).to(dev)
             L = _lib.lib()
             chosen = (ill.precision, ref.precision)
 
@@ -269,18 +291,20 @@ class DRMNet(nn.Module):
                 ill.auto_override("f16x3", why)
                 ref.auto_override("f16x3", why)
             ac["report"] = {"kept": kept, "rel_l2_chain_vs_f16x3": err, "rows": [float(f"{r:.3e}") for r in rows], "steps": ac["steps"], "tolerance": ac["tolerance"],
-                            "modes": {"illnet": chosen[0], "refnet": chosen[1]}, "probe": f"{B}x3x{H}x{W} seeded refmaps, {ac['steps']} reverse steps, worst row"}
+                            "modes": {"illnet": chosen[0], "refnet": chosen[1]}, "probe_source": "caller" if data is not None else "synthetic",
+                            "probe": f"{B}x3x{H}x{W} {'rows of the caller' if data is not None else 'seeded refmaps'}, {ac['steps']} reverse steps, worst row"}
             ac["done"][key] = ac["report"]
         finally:
             ac["busy"] = False
 
     # ------------------------------------------------------------------ the device sampler
-    def _engine(self):
-        """_engine_raw() behind the auto mode's chain probe (which may move both networks to f16x3 for the current weights)."""
+    def _engine(self, data: Optional[torch.Tensor] = None):
+        """_engine_raw() behind the auto mode's chain probe (which may move both networks to f16x3 for the current weights); ``data``: the refmaps
+        the caller is about to sample from -- the chain probe runs on rows of them (once per weight signature)."""
         h = self._engine_raw()
         ac = getattr(self, "_auto_chain", None)
         if ac is not None and not ac["busy"]:
-            self._auto_chain_probe(getattr(self, "_weight_set", "live"))
+            self._auto_chain_probe(getattr(self, "_weight_set", "live"), data)
             h = self._engine_raw()
         return h
 
@@ -316,14 +340,21 @@ class DRMNet(nn.Module):
             _lib.check(_lib.lib().drm_drmnet_create(hi, hr, _lib.ptr_array(zp), C.byref(cfg), C.byref(h)))
         if getattr(self, "_batch_parts", None) is not None:
             _lib.check(_lib.lib().drm_drmnet_set_batch_parts(h, int(self._batch_parts)))
+        if getattr(self, "_batch_part_min", None) is not None:
+            _lib.check(_lib.lib().drm_drmnet_set_batch_part_min(h, int(self._batch_part_min)))
         self._samplers[which] = (h, sig)
         return h
 
-    def set_batch_parts(self, parts: int):
-        """Row ranges a reverse step is forked into on internal streams (drm_drmnet_set_batch_parts; library default 2 from 64 rows per part, 1 = off)."""
+    def set_batch_parts(self, parts: int, min_rows: int = None):
+        """Row ranges a reverse step is forked into on internal streams (drm_drmnet_set_batch_parts; library default 2 from 64 rows per part, 1 = off).
+        min_rows: rows per part from which the fork engages (drm_drmnet_set_batch_part_min; tests pass 1)."""
         self._batch_parts = int(parts)
+        if min_rows is not None:
+            self._batch_part_min = int(min_rows)
         for h, _ in getattr(self, "_samplers", {}).values():
             _lib.check(_lib.lib().drm_drmnet_set_batch_parts(h, int(parts)))
+            if min_rows is not None:
+                _lib.check(_lib.lib().drm_drmnet_set_batch_part_min(h, int(min_rows)))
         return self
 
     def _free_sampler(self, which=None):
@@ -367,7 +398,7 @@ class DRMNet(nn.Module):
         step_noise = None if step_noise is None else _lib.require_gpu_tensor(step_noise, "step_noise")
         if step_noise is not None and tuple(step_noise.shape) != (self.max_timesteps, B, 3, H, W):
             raise RuntimeError("step_noise must be [max_timesteps, B, 3, H, W]")
-        h = self._engine()
+        h = self._engine(LrK)
         L = _lib.lib()
         ws = self._ws.get(int(L.drm_drmnet_workspace_bytes(h, B, H, W)), dev)
         Lr0 = torch.empty_like(LrK)

@@ -166,12 +166,14 @@ class LatentDiffusion(DDPM):
             self.init_from_ckpt(ckpt_path, list(ignore_keys))
         self._ws = _lib.Workspace()
 
-    def set_precision(self, precision: str):
+    def set_precision(self, precision: str, probe=None):
         """Conv arithmetic of the U-Net: "fp32" (exact fp32 MFMA), "f16x3" (split fp16, fp32-accurate, ~2.5x faster), "f16mx" (f16x3 with
         fp8 cross terms on the 3x3 convs: ~4e-5 per forward, ~3x faster) or "f16" (reduced precision)."""
         self.model.diffusion_model.set_precision(precision)
         # "auto": the per-network probe (unet.py) + a chain probe before f16mx is kept (_auto_chain_probe)
-        self._auto_chain = {"tolerance": 5e-5, "steps": 8, "done": {}, "busy": False, "report": None} if precision == "auto" else None
+        # ``probe`` [n,3,H,W]: conditioning refmaps of the CALLER for the chain probe; without it the first batch a sampler sees is handed to it
+        self._auto_chain = {"tolerance": 5e-5, "steps": 8, "done": {}, "busy": False, "report": None,
+                            "probe": None if probe is None else _lib.require_gpu_tensor(probe, "probe").detach()} if precision == "auto" else None
         return self
 
     @property
@@ -179,24 +181,38 @@ class LatentDiffusion(DDPM):
         ac = getattr(self, "_auto_chain", None)
         return None if ac is None else ac["report"]
 
-    def calibrate_precision(self):
-        """Auto mode: runs the network's probe and the chain probe now (weights on a GPU); returns the chain report."""
+    def calibrate_precision(self, probe=None):
+        """Auto mode: runs the network's probe and the chain probe now (weights on a GPU); returns the chain report.  ``probe``: conditioning refmaps
+        of the caller to run the chain on (re-measured for these rows)."""
+        ac = getattr(self, "_auto_chain", None)
+        if ac is not None and probe is not None:
+            ac["probe"] = _lib.require_gpu_tensor(probe, "probe").detach()
+            ac["done"] = {k: v for k, v in ac["done"].items() if k[-1] != "data"}
         self.model.diffusion_model.calibrate_precision()
         self._auto_chain_probe()
         return self.auto_chain_report
 
     @torch.no_grad()
-    def _auto_chain_probe(self) -> None:
+    def _auto_chain_probe(self, data=None) -> None:
         """Where the U-Net's own probe settled on f16mx: the first eight steps of the DDIM-50 chain (eta = 1, Philox noise from a fixed key: the steps with the
-        largest 1 / sqrt(alpha_bar) amplification) from a seeded x_T and two seeded conditioning refmaps at 128x128, in f16mx and in f16x3; f16mx is kept
-        only if every row of the state agrees to `tolerance` (5e-5, half the contract), otherwise the network runs in f16x3 for these weights."""
+        largest 1 / sqrt(alpha_bar) amplification) from a seeded x_T, in f16mx and in f16x3; f16mx is kept only if every row of the state agrees to
+        `tolerance` (5e-5, half the contract), otherwise the network runs in f16x3 for these weights.  The conditioning rows: the CALLER's (``data`` = the
+        conditioning a sampler was called with, or the ``probe`` of set_precision / calibrate_precision; first and middle row at their own size), once
+        per weight signature -- else two seeded synthetic refmaps at 128x128."""
         ac = getattr(self, "_auto_chain", None)
         unet = self.model.diffusion_model
-        if ac is None or ac["busy"] or unet.auto_report is None or unet.precision != "f16mx":
+        if ac is None or ac["busy"] or unet.auto_report is None:
             return
-        key = (unet._active_set, unet.__dict__["_auto"]["sig"])
+        if data is None:
+            data = ac.get("probe")
+        sigs = (unet._active_set, unet.__dict__["_auto"]["sig"])
+        key = sigs + ("data" if data is not None else "synth",)
+        if key not in ac["done"] and data is None and sigs + ("data",) in ac["done"]:
+            key = sigs + ("data",)
         if key in ac["done"]:
             ac["report"] = ac["done"][key]
+            return
+        if unet.precision != "f16mx":
             return
         ac["busy"] = True
         try:
@@ -204,8 +220,13 @@ class LatentDiffusion(DDPM):
             from .ddim import DDIMSampler
 
             dev = next(unet.parameters()).device
-            B, H, W = 2, 128, 128
-            cond = synth.synth_refmaps(B, H, W, 4321).to(dev)
+            if data is not None:
+                cond = data[[0, data.shape[0] // 2]] if data.shape[0] > 1 else data[:1]
+                cond = cond.detach().to(dev, torch.float32).contiguous()
+                B, H, W = cond.shape[0], cond.shape[2], cond.shape[3]
+            else:
+                B, H, W = 2, 128, 128
+                cond = synth.synth_refmaps(B, H, W, 4321).to(dev)
             x_T = torch.randn((B, 3, H, W), generator=torch.Generator().manual_seed(20261004)).to(dev)
             smp = DDIMSampler(self)
             smp.make_schedule(50, ddim_eta=1.0, verbose=False)
@@ -225,7 +246,8 @@ class LatentDiffusion(DDPM):
             else:
                 unet.auto_override("f16x3", f"chain probe: {ac['steps']} DDIM steps differ from f16x3 by {err:.2e} > {ac['tolerance']:.0e}")
             ac["report"] = {"kept": kept, "rel_l2_chain_vs_f16x3": err, "rows": [float(f"{r:.3e}") for r in rows], "steps": ac["steps"], "tolerance": ac["tolerance"],
-                            "probe": f"{B}x3x{H}x{W}: first {ac['steps']} steps of the DDIM-50 chain (eta 1), worst row"}
+                            "probe_source": "caller" if data is not None else "synthetic",
+                            "probe": f"{B}x3x{H}x{W} {'conditioning rows of the caller' if data is not None else 'seeded refmaps'}: first {ac['steps']} steps of the DDIM-50 chain (eta 1), worst row"}
             ac["done"][key] = ac["report"]
         finally:
             ac["busy"] = False
@@ -277,7 +299,14 @@ class LatentDiffusion(DDPM):
         return np.ascontiguousarray(tab.detach().cpu().numpy().astype(np.float32))
 
     @torch.no_grad()
-    def _ddpm_loop(self, cond, shape, x_T=None, timesteps=None, start_T=None, noise=None, seed=None):
+    def _ddpm_loop(self, cond, shape, x_T=None, timesteps=None, start_T=None, noise=None, seed=None, mask=None, x0=None, mask_noise=None, blend_when=1,
+                   temperature=1.0):
+        """The ancestral chain on the device (drm_ddpm_sample).  mask / x0: the known-region blending of the reference's two loops --
+        ``blend_when`` 1 = LatentDiffusion.p_sample_loop (after p_sample, q_sample(x0, t): ddpm.py:1300-1302), 0 = ObsNetDiffusion.p_sample_loop (before
+        p_sample, x0 itself at t == 0, else q_sample(x0, t - 1): models/obsnet.py:545-547); ``mask_noise`` [T,N,C,H,W] injects q_sample's draws.
+        ``temperature`` scales the step noise (ddpm.py:1157: the exp(0.5 logvar) column)."""
+        if (mask is None) != (x0 is None):
+            raise ValueError("mask and x0 go together (ddpm.py:1286-1288)")
         dev = self.betas.device
         c = cond[0] if isinstance(cond, (list, tuple)) else cond
         c = _lib.require_gpu_tensor(c, "cond")
@@ -293,13 +322,34 @@ class LatentDiffusion(DDPM):
         unet = self.model.diffusion_model
         h = unet.engine_handle()
         if getattr(self, "_auto_chain", None) is not None:  # auto mode: the chain probe may move the network to f16x3 for these weights
-            self._auto_chain_probe()
+            self._auto_chain_probe(c)  # (on rows of the caller's conditioning, once per weight signature)
             h = unet.engine_handle()
         L = _lib.lib()
         n, _, hh, ww = shape
         ws = self._ws.get(int(L.drm_sampler_workspace_bytes(h, n, hh, ww)), dev)
         pred_x0 = torch.empty_like(img)
         coef = self.ddpm_coef_table()
+        if temperature != 1.0:
+            coef = coef.copy()
+            coef[:, 4] = (torch.from_numpy(coef[:, 4]) * float(temperature)).numpy()
+        if mask is not None:
+            sa = self.sqrt_alphas_cumprod.detach().cpu().float().numpy()
+            s1 = self.sqrt_one_minus_alphas_cumprod.detach().cpu().float().numpy()
+            q = np.zeros((T, 2), dtype=np.float32)
+            for j in range(T):
+                t = T - 1 - j
+                if blend_when == 1:
+                    q[j] = (sa[t], s1[t])
+                else:
+                    q[j] = (1.0, 0.0) if t == 0 else (sa[t - 1], s1[t - 1])
+            blend, keep = _lib.make_mask_blend(mask, x0, q, mask_noise, blend_when, tuple(img.shape))
+            with torch.cuda.device(dev):
+                _lib.check(L.drm_ddpm_sample_masked(h, img.data_ptr(), pred_x0.data_ptr(), c.data_ptr(), coef.ctypes.data_as(C.POINTER(C.c_float)), T,
+                                                    int(bool(self.clip_denoised)), _lib.ptr(noise), seed, C.byref(blend), n, hh, ww, ws.data_ptr(), ws.numel(),
+                                                    _lib.stream_ptr(dev)))
+            torch.cuda.current_stream(dev).synchronize()  # (the blend's tensors stay alive until the chain has run)
+            del keep
+            return img, pred_x0
         with torch.cuda.device(dev):
             _lib.check(L.drm_ddpm_sample(h, img.data_ptr(), pred_x0.data_ptr(), c.data_ptr(), coef.ctypes.data_as(C.POINTER(C.c_float)), T,
                                          int(bool(self.clip_denoised)), _lib.ptr(noise), seed, n, hh, ww, ws.data_ptr(), ws.numel(),
@@ -308,11 +358,12 @@ class LatentDiffusion(DDPM):
 
     @torch.no_grad()
     def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None,
-                      quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, noise=None, seed=None):
-        """ddpm.py:1253-1313 -> final img.  (intermediates: only the endpoints are kept; the loop runs on the device.)"""
-        if mask is not None or callback is not None or img_callback is not None or quantize_denoised:
-            raise NotImplementedError("mask / callbacks / quantize are not on the shipped path")
-        img, _ = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed)
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, noise=None, seed=None,
+                      mask_noise=None, temperature=1.0):
+        """ddpm.py:1253-1313 -> final img.  (intermediates: only the endpoints are kept; the loop runs on the device.)  mask / x0: ddpm.py:1300-1302."""
+        if callback is not None or img_callback is not None or quantize_denoised:
+            raise NotImplementedError("callbacks / quantize are not on the shipped path")
+        img, _ = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed, mask, x0, mask_noise, 1, temperature)
         if return_intermediates:
             return img, [img]
         return img
@@ -348,11 +399,13 @@ class ObsNetDiffusion(LatentDiffusion):
 
     @torch.no_grad()
     def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None,
-                      quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, noise=None, seed=None):
-        """models/obsnet.py:500-564: like LatentDiffusion.p_sample_loop but returns pred_x0 of the LAST step."""
-        if mask is not None or callback is not None or img_callback is not None or quantize_denoised:
-            raise NotImplementedError("mask / callbacks / quantize are not on the shipped path")
-        img, pred_x0 = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed)
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, noise=None, seed=None,
+                      mask_noise=None, temperature=1.0):
+        """models/obsnet.py:500-564: like LatentDiffusion.p_sample_loop but returns pred_x0 of the LAST step; mask / x0 blend BEFORE p_sample
+        (x0 itself at t == 0, else q_sample(x0, t - 1): models/obsnet.py:545-547)."""
+        if callback is not None or img_callback is not None or quantize_denoised:
+            raise NotImplementedError("callbacks / quantize are not on the shipped path")
+        img, pred_x0 = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed, mask, x0, mask_noise, 0, temperature)
         if return_intermediates:
             return pred_x0, {"x_inter": [img], "pred_x0": [pred_x0]}
         return pred_x0

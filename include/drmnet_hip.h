@@ -158,8 +158,13 @@ size_t drm_drmnet_workspace_bytes(const drm_drmnet* s, int N, int H, int W);
 /* Batch parts of a reverse step (default 2; 1 = off; at most 4): a step over at least 64 rows per part runs its row ranges on internal streams
  * forked from and joined back into `stream`, so the sparse launches of one range (deep levels, small kernels) overlap with the other's.  The rows
  * of the reference's loop are independent (models/drmnet.py:809-839): results are those of the ranges run one after the other.  Call before
- * drm_drmnet_workspace_bytes (the workspace covers the parts' slices). */
+ * drm_drmnet_workspace_bytes (the workspace covers the parts' slices); a workspace that does not hold the slices makes the step run unforked, not fail.
+ * NOT bitwise: a range of n / parts rows can take other tile shapes and split-K forms than the whole batch, so a row's result depends on the batch size
+ * and on `parts` at the level of the arithmetic mode's rounding (f16x3: < 2e-5 rel-L2 over a recorded loop). */
 int drm_drmnet_set_batch_parts(drm_drmnet* s, int parts);
+/* Rows per part from which a step is forked (default 64: below it the ranges fall to the narrow conv tiles and the overlap loses, 817 vs 852 steps/s at
+ * 32 rows); tests set 1 to drive tiny batches through the forked form.  Replaces the DRM_BATCH_PARTS / DRM_BATCH_PART_MIN environment reads of r5. */
+int drm_drmnet_set_batch_part_min(drm_drmnet* s, int rows);
 
 /* One reverse step on the active rows (DRMNet.p_mean_variance + the loop body, models/drmnet.py:752-770,809-839):
  *   z_out = RefNet(cat[Lr_k, LrK], i); zk = clamp(z0 + gamma^i (z_out - z0)); out = IllNet(cat[Lr_k, LrK], z_emb(zk - z0));
@@ -201,6 +206,31 @@ int drm_ddim_sample_logged(drm_unet* net, float* x, const float* cond, const int
  * x: in = x_T, out = last img; pred_x0: [N,3,H,W] out (what ObsNetDiffusion.p_sample_loop returns). */
 int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
                     const float* noise, uint64_t seed, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The samplers' `mask` / `x0` arguments (known-region blending): img = q_sample(x0, t) * mask + (1 - mask) * img with
+ * q_sample(x0, t) = sqrt(a_bar_t) x0 + sqrt(1 - a_bar_t) noise (ddpm.py:1052-1058).  Where and at which t it is applied differs between the three
+ * reference loops, so the caller supplies the (a, b) pair of every chain step and the side of the step:
+ *   DDIMSampler.ddim_sampling      ldm/models/diffusion/ddim.py:175-178   before the step's forward, at the step's t            -> when = 0
+ *   ObsNetDiffusion.p_sample_loop  models/obsnet.py:545-547               before p_sample: x0 itself at t == 0, else t - 1       -> when = 0
+ *   LatentDiffusion.p_sample_loop  ldm/models/diffusion/ddpm.py:1300-1302 after p_sample, at the step's t                       -> when = 1
+ * (`temperature` of p_sample_ddim / p_sample, ddim.py:255 / ddpm.py:1157, needs no entry point: it scales the sigma column of `coef`.) */
+typedef struct drm_mask_blend {
+  const float* mask;   /* [N, mask_channels, H, W], device */
+  int mask_channels;   /* 1 (broadcast over the channels) or 3 */
+  const float* x0;     /* [N,3,H,W], device */
+  const float* qcoef;  /* float[steps][2], host: (a, b) of chain step j (j = 0 is the first executed step) */
+  const float* qnoise; /* [steps][N,3,H,W] device (the draws of q_sample), or NULL: Philox(seed) under a key of its own */
+  int when;            /* 0 = before the step's network forward, 1 = after its update */
+} drm_mask_blend;
+
+/* drm_ddim_sample_logged / drm_ddpm_sample with the blending above (log_every_t <= 0: no intermediates).  Graph replay applies unchanged (the
+ * pairs live in a device table read through the step counter). */
+int drm_ddim_sample_masked(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
+                           const float* noise, uint64_t seed, const drm_mask_blend* blend, int log_every_t, float* log_x, float* log_pred_x0, int log_slots,
+                           int32_t* n_logged, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+int drm_ddpm_sample_masked(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
+                           const float* noise, uint64_t seed, const drm_mask_blend* blend, int N, int H, int W, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 size_t drm_sampler_workspace_bytes(const drm_unet* net, int N, int H, int W);
 

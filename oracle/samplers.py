@@ -108,9 +108,16 @@ def ddim_sample(
     step_noise: Sequence[torch.Tensor],
     sched: dict,
     num_steps: Optional[int] = None,
+    mask: Optional[torch.Tensor] = None,
+    x0: Optional[torch.Tensor] = None,
+    q_noise: Optional[Sequence[torch.Tensor]] = None,
+    q_coef: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+    temperature: float = 1.0,
 ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """ddim.py:171-204 + :206-259.  eps_model(xc, t) with xc = cat([x, cond], 1)
-    (DiffusionWrapper concat branch, ddpm.py:1527-1529).  Returns final x (not pred_x0)."""
+    (DiffusionWrapper concat branch, ddpm.py:1527-1529).  Returns final x (not pred_x0).
+    mask / x0 (ddim.py:175-178): before every step x = q_sample(x0, t) * mask + (1 - mask) * x with q_sample = sqrt_alphas_cumprod[t] x0 +
+    sqrt_one_minus_alphas_cumprod[t] q_noise[j] (ddpm.py:1052-1058; q_coef = those two fp32 tables); temperature scales the step noise (ddim.py:255)."""
     tau = sched["ddim_timesteps"]
     coef = ddim_step_coeffs(sched)
     total = len(tau)
@@ -121,10 +128,13 @@ def ddim_sample(
         if num_steps is not None and j >= num_steps:
             break
         t = torch.full((b,), int(tau[index]), dtype=torch.long)
+        if mask is not None:
+            ti = int(tau[index])
+            x = (q_coef[0][ti] * x0 + q_coef[1][ti] * q_noise[j]) * mask + (1.0 - mask) * x
         e = eps_model(torch.cat([x, cond], dim=1), t)
         sa, s1m, sap, sdir, sig = (torch.tensor(float(v)) for v in coef[index])
         pred_x0 = (x - s1m * e) / sa
-        x = sap * pred_x0 + sdir * e + sig * step_noise[j]
+        x = sap * pred_x0 + sdir * e + sig * step_noise[j] * temperature
         xs.append(x)
     return x, xs
 
@@ -142,8 +152,19 @@ def ddpm_sample(
     timesteps: Optional[int] = None,
     start_T: Optional[int] = None,
     clip_denoised: bool = False,
+    mask: Optional[torch.Tensor] = None,
+    x0: Optional[torch.Tensor] = None,
+    q_noise: Optional[Sequence[torch.Tensor]] = None,
+    blend: str = "obsnet",
+    temperature: float = 1.0,
+    t_list: Optional[Sequence[int]] = None,
 ):
-    """obsnet.py:500-564 over ddpm.py:1079-1167.  Returns (pred_x0_last, img_last, [img per step])."""
+    """obsnet.py:500-564 over ddpm.py:1079-1167.  Returns (pred_x0_last, img_last, [img per step]).
+    mask / x0: blend = "obsnet" (models/obsnet.py:545-547: BEFORE p_sample, img_orig = x0 at t == 0 else q_sample(x0, t - 1)) or "ldm"
+    (ddpm.py:1300-1302: AFTER p_sample, q_sample(x0, t)); temperature scales the step noise (ddpm.py:1157); t_list: explicit timesteps (p_sample calls)."""
+    def q_sample(t, nz):  # ddpm.py:1052-1058
+        return S["sqrt_alphas_cumprod"][t] * x0 + S["sqrt_one_minus_alphas_cumprod"][t] * nz
+
     T = S["betas"].shape[0] if timesteps is None else timesteps
     if start_T is not None:
         T = min(T, start_T)
@@ -151,8 +172,11 @@ def ddpm_sample(
     b = img.shape[0]
     imgs = []
     pred_x0 = None
-    for j, i in enumerate(range(T - 1, -1, -1)):
+    for j, i in enumerate(range(T - 1, -1, -1) if t_list is None else t_list):
         t = torch.full((b,), i, dtype=torch.long)
+        if mask is not None and blend == "obsnet":
+            img_orig = x0 if i == 0 else q_sample(i - 1, q_noise[j])
+            img = img_orig * mask + (1.0 - mask) * img
         e = eps_model(torch.cat([img, cond], dim=1), t)
         x_recon = S["sqrt_recip_alphas_cumprod"][i] * img - S["sqrt_recipm1_alphas_cumprod"][i] * e  # ddpm.py:233-237
         if clip_denoised:
@@ -160,7 +184,9 @@ def ddpm_sample(
         mean = S["posterior_mean_coef1"][i] * x_recon + S["posterior_mean_coef2"][i] * img  # :239-246
         logvar = S["posterior_log_variance_clipped"][i]
         nonzero = 0.0 if i == 0 else 1.0
-        img = mean + nonzero * (0.5 * logvar).exp() * step_noise[j]  # :1156-1167
+        img = mean + nonzero * (0.5 * logvar).exp() * (step_noise[j] * temperature)  # :1156-1167
+        if mask is not None and blend == "ldm":
+            img = q_sample(i, q_noise[j]) * mask + (1.0 - mask) * img
         pred_x0 = x_recon
         imgs.append(img)
     return pred_x0, img, imgs

@@ -40,10 +40,8 @@ def test_forked_row_ranges_of_the_drmnet_step_many_repetitions(monkeypatch):
     from test_gpu_samplers import tiny_drmnet
 
     dev = torch.device("cuda:0")
-    monkeypatch.setenv("DRM_BATCH_PART_MIN", "1")
-    monkeypatch.setenv("DRM_BATCH_PARTS", "3")
     g = gold("drmnet_loop_b")
-    m = tiny_drmnet(g, dev).set_precision("f16mx")
+    m = tiny_drmnet(g, dev).set_precision("f16mx").set_batch_parts(3, min_rows=1)
     from drmnet_amd import synth
 
     x = synth.synth_refmaps(9, 16, 16, synth.SEED_INPUT).to(dev)

@@ -311,7 +311,11 @@ def test_auto_precision_chain_probe_overrules_the_single_forward_probe(dev):
     assert rep["kept"] and rep["rel_l2_chain_vs_f16x3"] <= rep["tolerance"] and ill.precision == ref.precision == "f16mx"
     LrK = synth.synth_refmaps(2, 16, 32, 5).to(dev)
     out_auto = m.p_sample_loop(LrK, [LrK], [LrK], verbose=False, seed=3, early_exit=False)[0]
-    assert m.calibrate_precision() is rep  # measured once for these weights
+    # [r6] the first batch the sampler sees is handed to the chain probe (rows of the caller, once per weight signature): that record stands from then on
+    rep_d = m.auto_chain_report
+    assert rep_d is not rep and rep_d["probe_source"] == "caller" and rep["probe_source"] == "synthetic" and rep_d["kept"]
+    m.p_sample_loop(LrK, [LrK], [LrK], verbose=False, seed=4, early_exit=False)
+    assert m.calibrate_precision() is rep_d  # measured once for these weights
 
     # the case the chain probe exists for, as it occurs: every network passes its single-forward probe at 1e-3 (1.2e-4 / 1.7e-5), and eight steps of the
     # undamped tiny sampler blow the f16mx-vs-f16x3 difference up to ~3e-3 -- the SAME bar applied to the chain sends both networks to f16x3
@@ -343,6 +347,92 @@ def test_auto_precision_chain_probe_overrules_the_single_forward_probe(dev):
     obs.model.diffusion_model._set_mode("f16mx")
     obs._auto_chain_probe()
     assert obs.model.diffusion_model.precision == "f16x3" and not obs.auto_chain_report["kept"]
+
+
+def test_auto_precision_gates_on_the_callers_batch(dev):
+    """[r6, VERDICT r5 item 5b] The auto gate decides on the CALLER's data: p_sample_loop / ddim_sampling hand rows of their first batch to the chain
+    probe (set_precision("auto", probe=...) / calibrate_precision(probe=...) take them explicitly), so the error that decides is the one measured on
+    those rows, not on the seeded synthetic pair.  Shown on the tiny sampler: the caller-probe measures its own number (different rows, different
+    size than the synthetic probe); a tolerance just below that number flips both networks to f16x3 (bit-identical to an f16x3 model from then on),
+    a tolerance just above keeps f16mx; another batch of the same model does not re-measure; new data through calibrate_precision(probe=) does."""
+    from drmnet_amd.drmnet import DRMNet
+    from drmnet_amd.obsnet import ObsNetDiffusion
+
+    unet_t = {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(ou.TINY_UNET_CFG)}
+    enc_t = {"target": "ldm.modules.diffusionmodules.openaimodel.EncoderUNetModel", "params": dict(ou.TINY_ENC_CFG)}
+
+    def build(chain_tol, probe=None):
+        m = DRMNet(illnet_config=unet_t, refnet_config=enc_t, max_timesteps=12, image_size=16, concat_mode=True, use_ema=False, gamma=0.9, epsilon=0.01, delta=0.025,
+                   z0=[1, 1, 1, 1, 0, 1], brdf_param_names=["p"] * 6)
+        synth.load_synth(m.illnet_model.diffusion_model, 21)
+        synth.load_synth(m.refnet_model.diffusion_model, 22)
+        zman = [(k, tuple(v.shape)) for k, v in m.illnet_model.z_emb_layer.state_dict().items()]
+        m.illnet_model.z_emb_layer.load_state_dict(synth.synth_state_dict(zman, synth.SEED_ZEMB))
+        m = m.to(dev)
+        m.AUTO_CHAIN_TOLERANCE = chain_tol
+        m.set_precision("auto", probe=probe)
+        for net in (m.illnet_model.diffusion_model, m.refnet_model.diffusion_model):
+            net.set_precision_auto(tolerance=1e-2)  # (per-network bar where the tiny networks pass it: the chain bar decides, as in the test above)
+        return m
+
+    LrK = synth.synth_refmaps(5, 16, 32, 5).to(dev)
+    kw = dict(verbose=False, seed=3, early_exit=False)
+    m = build(1.0)
+    out = m.p_sample_loop(LrK, [LrK], [LrK], **kw)[0]
+    rep = m.auto_chain_report
+    e = rep["rel_l2_chain_vs_f16x3"]
+    print(f"caller-batch chain probe (tiny DRMNet, rows 0 and 2 of a 5x3x16x32 batch): {rep}")
+    assert rep["probe_source"] == "caller" and rep["probe"].startswith("2x3x16x32 rows of the caller") and rep["kept"] and 0 < e < 1.0
+    rep_s = build(1.0).calibrate_precision()  # no data yet: the synthetic pair at 128 x 128 -- another measurement
+    assert rep_s["probe_source"] == "synthetic" and rep_s["rel_l2_chain_vs_f16x3"] != e
+    m.p_sample_loop(LrK.flip(0), [LrK.flip(0)], [LrK.flip(0)], **kw)
+    assert m.auto_chain_report is rep  # the next batch re-measures nothing
+    # the same rows against a bar just below / just above what they measure
+    m_lo, m_hi = build(e * 0.5), build(e * 2.0)
+    out_lo = m_lo.p_sample_loop(LrK, [LrK], [LrK], **kw)[0]
+    out_hi = m_hi.p_sample_loop(LrK, [LrK], [LrK], **kw)[0]
+    assert not m_lo.auto_chain_report["kept"] and m_lo.illnet_model.diffusion_model.precision == m_lo.refnet_model.diffusion_model.precision == "f16x3"
+    assert "chain probe" in m_lo.illnet_model.diffusion_model.auto_report["overridden_by"]
+    assert m_hi.auto_chain_report["kept"] and "f16mx" in (m_hi.illnet_model.diffusion_model.precision, m_hi.refnet_model.diffusion_model.precision)
+    assert abs(m_lo.auto_chain_report["rel_l2_chain_vs_f16x3"] - e) <= 1e-3 * e and abs(m_hi.auto_chain_report["rel_l2_chain_vs_f16x3"] - e) <= 1e-3 * e
+    x3 = build(1.0).set_precision("f16x3")
+    assert torch.equal(out_lo, x3.p_sample_loop(LrK, [LrK], [LrK], **kw)[0])  # flipped: it really runs in f16x3
+    assert torch.equal(out_hi, out)
+    # explicit probe rows: set_precision("auto", probe=...) measures on them before any sampling; calibrate_precision(probe=...) re-measures on new ones
+    hdr = LrK * 1.0e4  # (a 1e4-range HDR refmap batch)
+    m_p = build(1.0, probe=hdr)
+    rep_p = m_p.calibrate_precision()
+    assert rep_p["probe_source"] == "caller" and rep_p["rel_l2_chain_vs_f16x3"] != e
+    rep_q = m_p.calibrate_precision(probe=LrK)
+    print(f"1e4-range HDR rows: {rep_p['rel_l2_chain_vs_f16x3']:.2e}; ordinary rows {rep_q['rel_l2_chain_vs_f16x3']:.2e}")
+    assert rep_q is not rep_p and abs(rep_q["rel_l2_chain_vs_f16x3"] - e) <= 1e-3 * e
+
+    # ObsNet: the conditioning of the first sampler call
+    from drmnet_amd.ddim import DDIMSampler
+
+    obs = ObsNetDiffusion(unet_config=unet_t, linear_start=1e-4, linear_end=0.09, log_every_t=2000, timesteps=1000, first_stage_key="LrK",
+                          cond_stage_key="raw_refmap", padding_mode="noise", image_size=16, channels=3, concat_mode=True, ddim_steps=50,
+                          clip_denoised=False, masked_loss=False, use_ema=False)
+    synth.load_synth(obs.model.diffusion_model, 23)
+    obs = obs.to(dev).set_precision("auto")
+    obs.model.diffusion_model.set_precision_auto(tolerance=1e-2)
+    obs._auto_chain["tolerance"] = 1.0
+    smp = DDIMSampler(obs)
+    smp.make_schedule(50, ddim_eta=1.0, verbose=False)
+    x, _ = smp.ddim_sampling(LrK, tuple(LrK.shape), seed=2, log_every_t=0, verbose=False)
+    rep_o = obs.auto_chain_report
+    print(f"caller-batch chain probe (tiny ObsNet): {rep_o}")
+    assert rep_o["probe_source"] == "caller" and rep_o["probe"].startswith("2x3x16x32 conditioning rows of the caller") and torch.isfinite(x).all()
+    eo = rep_o["rel_l2_chain_vs_f16x3"]
+    obs2 = ObsNetDiffusion(unet_config=unet_t, linear_start=1e-4, linear_end=0.09, log_every_t=2000, timesteps=1000, first_stage_key="LrK",
+                           cond_stage_key="raw_refmap", padding_mode="noise", image_size=16, channels=3, concat_mode=True, ddim_steps=50,
+                           clip_denoised=False, masked_loss=False, use_ema=False)
+    synth.load_synth(obs2.model.diffusion_model, 23)
+    obs2 = obs2.to(dev).set_precision("auto")
+    obs2.model.diffusion_model.set_precision_auto(tolerance=1e-2)
+    obs2._auto_chain["tolerance"] = eo * 0.5
+    obs2.p_sample_loop(LrK, tuple(LrK.shape), verbose=False, start_T=3, seed=2)  # (the ancestral loop hands its conditioning over too)
+    assert not obs2.auto_chain_report["kept"] and obs2.model.diffusion_model.precision == "f16x3" and obs2.auto_chain_report["probe_source"] == "caller"
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

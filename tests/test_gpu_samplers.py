@@ -81,16 +81,14 @@ def test_drmnet_step_over_forked_batch_parts_equals_the_single_stream_step(dev, 
     """drm_drmnet_set_batch_parts: the row ranges of a step on internal streams (forked from / joined into the caller's stream) give what the
     single-stream step gives -- through the reference trace (rows leave the loop at different steps: the ranges shrink and collapse to one), the
     host-driven per-step entry point, and a batch that is not a multiple of the parts.  The parts engage from 64 rows each in the product;
-    DRM_BATCH_PART_MIN (read when the sampler is created) lets a tiny batch through them."""
+    drm_drmnet_set_batch_part_min lets a tiny batch through them."""
     g = gold("drmnet_loop_b")
     LrK = torch.from_numpy(g["LrK"]).to(dev)
     n0 = torch.from_numpy(g["noise0"]).to(dev)
     sn = torch.from_numpy(g["step_noise"]).to(dev)
     ref = tiny_drmnet(g, dev).set_precision("f16x3")
     Lr0_1, zK_1, K_1 = ref.p_sample_loop(LrK, [LrK], [LrK], verbose=False, noise0=n0, step_noise=sn)
-    monkeypatch.setenv("DRM_BATCH_PART_MIN", "1")
-    monkeypatch.setenv("DRM_BATCH_PARTS", str(parts))
-    m = tiny_drmnet(g, dev).set_precision("f16x3")
+    m = tiny_drmnet(g, dev).set_precision("f16x3").set_batch_parts(parts, min_rows=1)
     Lr0, zK, K = m.p_sample_loop(LrK, [LrK], [LrK], verbose=False, noise0=n0, step_noise=sn)
     assert K.cpu().tolist() == g["K"].tolist() == K_1.cpu().tolist()
     # (a range of 1-2 rows takes other tile shapes / split-K forms than the whole batch: equal to f16x3 rounding, not bitwise)
@@ -172,6 +170,58 @@ def test_ddpm_ancestral_vs_reference_trace(dev, precision):
     e_x0 = rel_l2(pred_x0.cpu(), g["pred_x0"])
     print(f"ddpm 6 steps ({precision}): img {e_img:.2e} pred_x0 {e_x0:.2e}")
     assert (e_img < 1e-5 and e_x0 < 1e-5) if precision != "f16mx" else (e_img < CONTRACT and e_x0 < CONTRACT)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_sampler_mask_x0_temperature_vs_reference_traces(dev, precision):
+    """[r6, VERDICT r5 item 9] the samplers' `mask` / `x0` / `temperature` arguments on the device loops (mask_blend_kernel + the sigma column), against
+    the reference's own three loops: DDIMSampler.sample(mask=, x0=, temperature=0.7) (ddim.py:175-178, :255; 50 steps, one-channel binary and
+    three-channel soft masks), ObsNetDiffusion.p_sample_loop(mask=, x0=) (blend before p_sample at t - 1, models/obsnet.py:545-547) and
+    LatentDiffusion.p_sample_loop(mask=, x0=) (blend after p_sample at t, ddpm.py:1300-1302); graph replay == eager; Philox q-noise runs."""
+    from drmnet_amd import ops
+    from drmnet_amd.ddim import DDIMSampler
+    from drmnet_amd.obsnet import LatentDiffusion
+
+    g = gold("sampler_masks")
+    m = tiny_obsnet(dev).set_precision(precision)
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    cond, x_T, x0, noise, qnoise = T("cond"), T("x_T"), T("x0"), T("noise"), T("qnoise")
+    temp = float(g["temperature"])
+    tol = 2e-5 if precision != "f16mx" else CONTRACT
+    s = DDIMSampler(m)
+    for tag in ("m1", "m3"):
+        mk = T("mask1" if tag == "m1" else "mask3")
+        x, inter = s.sample(50, 3, (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, mask=mk, x0=x0, temperature=temp, mask_noise=qnoise, log_every_t=1)
+        e1, e = rel_l2(inter["x_inter"][1].cpu(), g[f"ddim_{tag}_x_inter"][0]), rel_l2(x.cpu(), g[f"ddim_{tag}_x"])
+        print(f"ddim mask {tag} ({precision}): first step {e1:.2e}, 50 steps {e:.2e}")
+        assert e1 < tol and e < tol and len(inter["x_inter"]) == 51
+        x_nolog, _ = s.sample(50, 3, (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, mask=mk, x0=x0, temperature=temp, mask_noise=qnoise, log_every_t=0)
+        assert torch.equal(x_nolog, x)
+    pred_x0, inter = m.p_sample_loop(cond, tuple(x_T.shape), return_intermediates=True, x_T=x_T, verbose=False, start_T=6, noise=noise[:6], mask=T("mask1"), x0=x0,
+                                     mask_noise=qnoise[:6])
+    e_img, e_x0 = rel_l2(inter["x_inter"][-1].cpu(), g["obs_x_inter"][-1]), rel_l2(pred_x0.cpu(), g["obs_pred_x0"])
+    img = LatentDiffusion.p_sample_loop(m, cond, tuple(x_T.shape), x_T=x_T, verbose=False, start_T=6, noise=noise[:6], mask=T("mask3"), x0=x0, mask_noise=qnoise[:6])
+    e_ldm = rel_l2(img.cpu(), g["ldm_x"])
+    print(f"ddpm masks ({precision}): obsnet form img {e_img:.2e} pred_x0 {e_x0:.2e}; ldm form {e_ldm:.2e}")
+    assert e_img < tol and e_x0 < tol and e_ldm < tol
+    # temperature alone on the ancestral loop == the noise tensor scaled by it (same kernel path, the sigma column carries the factor)
+    a = m.p_sample_loop(cond, tuple(x_T.shape), x_T=x_T, verbose=False, start_T=6, noise=noise[:6], temperature=temp)
+    b = m.p_sample_loop(cond, tuple(x_T.shape), x_T=x_T, verbose=False, start_T=6, noise=noise[:6] * temp)
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6
+    # graph replay of the masked chain is the eager chain, bit for bit
+    ops.set_graph_replay(True)
+    try:
+        xg, _ = s.sample(50, 3, (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, noise=noise, mask=T("mask3"), x0=x0, temperature=temp, mask_noise=qnoise, log_every_t=0)
+    finally:
+        ops.set_graph_replay(False)
+    assert torch.equal(xg, x)
+    # Philox q-noise: runs, finite, known region pulled towards x0 (binary mask, last blend at t = ddim_timesteps[0] = 1: almost x0 itself before the last step)
+    xp, _ = s.sample(50, 3, (3, 16, 16), cond, eta=0.0, x_T=x_T, verbose=False, seed=5, mask=T("mask1"), x0=x0, log_every_t=0)
+    assert torch.isfinite(xp).all()
+    with pytest.raises(ValueError):
+        s.sample(50, 3, (3, 16, 16), cond, eta=0.0, x_T=x_T, verbose=False, seed=5, mask=T("mask1"))
+    with pytest.raises(NotImplementedError):
+        s.sample(50, 3, (3, 16, 16), cond, eta=0.0, x_T=x_T, verbose=False, seed=5, unconditional_guidance_scale=2.0, unconditional_conditioning=cond)
 
 
 def test_step_dropins_match_reference_named_methods(dev):

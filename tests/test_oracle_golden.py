@@ -215,6 +215,34 @@ def test_ddpm_trace():
     assert rel_l2(pred_x0, g["pred_x0"]) < 1e-4
 
 
+def test_sampler_mask_x0_temperature_traces():
+    """[r6] the samplers' mask / x0 / temperature arguments as the reference applies them (fixtures from its own three loops + p_sample):
+    DDIM before the step at the step's t (ddim.py:175-178) with temperature 0.7 (:255); ObsNetDiffusion.p_sample_loop before p_sample at t - 1
+    (models/obsnet.py:545-547); LatentDiffusion.p_sample_loop after p_sample at t (ddpm.py:1300-1302); p_sample(temperature=) (ddpm.py:1157)."""
+    g = gold("sampler_masks")
+    Pu, _, _, tu, _ = tiny_nets()
+    S = osamp.ddpm_schedule(1000, 1e-4, 0.09)
+    d = osamp.ddim_schedule(S["alphas_cumprod"], 1000, 50, 1.0)
+    eps_model = lambda xc, t: ou.unet_forward(Pu, tu, xc, timesteps=t)
+    T = lambda k: torch.from_numpy(g[k])
+    qc = (S["sqrt_alphas_cumprod"], S["sqrt_one_minus_alphas_cumprod"])
+    temp = float(g["temperature"])
+    for tag, mk in (("m1", T("mask1")), ("m3", T("mask3"))):
+        x, xs = osamp.ddim_sample(eps_model, T("cond"), T("x_T"), T("noise"), d, mask=mk, x0=T("x0"), q_noise=T("qnoise"), q_coef=qc, temperature=temp)
+        assert rel_l2(xs[0], g[f"ddim_{tag}_x_inter"][0]) < TOL and rel_l2(xs[5], g[f"ddim_{tag}_x_inter"][5]) < 5 * TOL
+        assert rel_l2(x, g[f"ddim_{tag}_x"]) < 2e-4  # 50-step chain
+    pred_x0, img, imgs = osamp.ddpm_sample(eps_model, T("cond"), T("x_T"), T("noise"), S, start_T=6, mask=T("mask1"), x0=T("x0"), q_noise=T("qnoise"), blend="obsnet")
+    assert rel_l2(imgs[0], g["obs_x_inter"][0]) < TOL and rel_l2(img, g["obs_x_inter"][-1]) < 1e-4 and rel_l2(pred_x0, g["obs_pred_x0"]) < 1e-4
+    _, img, imgs = osamp.ddpm_sample(eps_model, T("cond"), T("x_T"), T("noise"), S, start_T=6, mask=T("mask3"), x0=T("x0"), q_noise=T("qnoise"), blend="ldm")
+    assert rel_l2(imgs[0], g["ldm_x_inter"][0]) < TOL and rel_l2(img, g["ldm_x"]) < 1e-4
+    # the blends are not no-ops, and the two DDPM forms differ
+    _, plain, _ = osamp.ddpm_sample(eps_model, T("cond"), T("x_T"), T("noise"), S, start_T=6)
+    assert rel_l2(plain, g["ldm_x"]) > 1e-2 and rel_l2(plain, g["obs_x_inter"][-1]) > 1e-2
+    _, _, imgs = osamp.ddpm_sample(eps_model, T("cond"), T("x_T"), T("noise"), S, temperature=temp, t_list=[int(t) for t in g["temp_t"]])
+    for k in range(3):
+        assert rel_l2(imgs[k], g["temp_x"][k]) < 5 * TOL
+
+
 def full_sampler_inputs():
     """Regenerates the seeded inputs of tests/golden/full_obsnet_sampler_steps.npz (tools/make_golden.py make_full_samplers)."""
     g = gold("full_obsnet_sampler_steps")

@@ -377,6 +377,69 @@ def make_obsnet_samplers():
         refddim.noise_like, refddpm.noise_like = o1, o2
 
 
+def make_sampler_masks():
+    """The samplers' mask / x0 / temperature arguments, from the reference's own loops on the tiny ObsNet (B = 3 @16x16):
+    DDIMSampler.sample(mask=, x0=, temperature=0.7) over 50 steps (ddim.py:175-178, :255), ObsNetDiffusion.p_sample_loop(mask=, x0=) over 6 steps
+    (blend BEFORE p_sample, x0 / q_sample(x0, t - 1): models/obsnet.py:545-547), LatentDiffusion.p_sample_loop(mask=, x0=) over 6 steps (blend AFTER
+    p_sample, q_sample(x0, t): ddpm.py:1300-1302), and two p_sample calls with temperature = 0.7 (ddpm.py:1157).  q_sample's draws are injected."""
+    import ldm.models.diffusion.ddim as refddim
+    import ldm.models.diffusion.ddpm as refddpm
+
+    m, DDIM = tiny_obsnet()
+    B, h, w = 3, 16, 16
+    g = gen(77)
+    cond = synth.synth_refmaps(B, h, w, 98) * 2 - 1
+    x0 = synth.synth_refmaps(B, h, w, 99) * 2 - 1
+    x_T = torch.randn((B, 3, h, w), generator=g)
+    noise = torch.randn((50, B, 3, h, w), generator=g)
+    qnoise = torch.randn((50, B, 3, h, w), generator=g)
+    mask1 = (torch.rand((B, 1, h, w), generator=g) > 0.5).float()      # one channel, broadcast
+    mask3 = torch.rand((B, 3, h, w), generator=g)                       # per-channel soft mask
+    ctr = {"i": 0, "q": 0}
+
+    def noise_like(shape, device, repeat=False):
+        out = noise[ctr["i"]]
+        ctr["i"] += 1
+        assert tuple(out.shape) == tuple(shape)
+        return out
+
+    q_orig = m.q_sample
+
+    def q_sample(x_start, t, noise=None):
+        out = q_orig(x_start, t, noise=qnoise[ctr["q"]])
+        ctr["q"] += 1
+        return out
+
+    o1, o2 = refddim.noise_like, refddpm.noise_like
+    refddim.noise_like = noise_like
+    refddpm.noise_like = noise_like
+    m.q_sample = q_sample
+    out = dict(cond=cond, x0=x0, x_T=x_T, noise=noise, qnoise=qnoise, mask1=mask1, mask3=mask3, temperature=0.7)
+    try:
+        for tag, mk in (("m1", mask1), ("m3", mask3)):
+            ctr.update(i=0, q=0)
+            x, inter = DDIM(m).sample(50, B, (3, h, w), cond, eta=1.0, x_T=x_T, verbose=False, log_every_t=1, mask=mk, x0=x0, temperature=0.7)
+            out[f"ddim_{tag}_x"] = x
+            out[f"ddim_{tag}_x_inter"] = torch.stack(inter["x_inter"][1:])
+        ctr.update(i=0, q=0)
+        pred_x0, inter = m.p_sample_loop(cond, (B, 3, h, w), return_intermediates=True, x_T=x_T, verbose=False, start_T=6, log_every_t=1, mask=mask1, x0=x0)
+        out.update(obs_pred_x0=pred_x0, obs_x_inter=torch.stack(inter["x_inter"][1:]))
+        ctr.update(i=0, q=0)
+        img, inter = refddpm.LatentDiffusion.p_sample_loop(m, cond, (B, 3, h, w), return_intermediates=True, x_T=x_T, verbose=False, start_T=6, log_every_t=1,
+                                                           mask=mask3, x0=x0)
+        out.update(ldm_x=img, ldm_x_inter=torch.stack(inter[1:]))
+        ctr.update(i=0, q=0)
+        xs, img = [], x_T
+        for t in (5, 4, 0):
+            img = refddpm.LatentDiffusion.p_sample(m, img, cond, torch.full((B,), t, dtype=torch.long), clip_denoised=False, temperature=0.7)
+            xs.append(img)
+        out.update(temp_x=torch.stack(xs), temp_t=np.asarray([5, 4, 0]))
+    finally:
+        refddim.noise_like, refddpm.noise_like = o1, o2
+        del m.q_sample
+    save("sampler_masks", **out)
+
+
 def make_full_samplers():
     """Full-width ObsNet (configs/obsnet/eval_obsnet.yaml, 147.6 M parameters by the synth rule) at the metric shape 3x128x256:
     the first two DDIM steps (eta = 1; ddim.py:206-259 p_sample_ddim at index 49, 48) and the first two ancestral steps
@@ -977,6 +1040,7 @@ STEPS = {
     "estimate_chain_full": lambda oa: make_estimate_chain(full=True),
     "full_sizes": lambda oa: make_full_sizes(oa),
     "obsnet_samplers": lambda oa: make_obsnet_samplers(),
+    "sampler_masks": lambda oa: make_sampler_masks(),
     "full": lambda oa: make_full_nets(oa),
     "full_samplers": lambda oa: make_full_samplers(),
     "transforms": lambda oa: make_transforms(),
