@@ -107,6 +107,8 @@ def estimate_batch(DRMNet_model, ObsNet_model, input_imgs: torch.Tensor, input_n
 
 
 def main(argv=None):
+    # Provenance: this entry point deliberately mirrors the reference's command line (scripts/estimate.py:105-142: the same options, defaults, mask
+    # rule and output files -- SURVEY 2 #20 keeps it as the user-facing surface); everything it calls is this package's own code over the HIP library.
     from . import file_io
     from .config import instantiate_from_config, load_config
     from .transform import hdr2ldr

@@ -205,6 +205,44 @@ def make_full_nets(oa):
             save(f"full_{name}_{h}x{w}", out=out, t=t, seed=seed, wsum=cs, xsum=synth.checksum(xc), tembsum=synth.checksum(t_emb))
 
 
+FULL_ROWS = (0, 13, 31)
+
+
+def full_rows_inputs(B=32, h=128, w=256):
+    """32 DISTINCT rows at the metric shape: refmaps, noised copies, per-row embeddings and per-row timesteps (regenerable: seeds 4242 / 4243)."""
+    x = synth.synth_refmaps(B, h, w, 4242)
+    g = gen(4243)
+    xk = x + 0.025 * torch.randn(x.shape, generator=g)
+    t_emb = torch.randn((B, 128), generator=g) * (0.25 + torch.arange(B, dtype=torch.float32) / 16.0)[:, None]
+    t = (torch.arange(B, dtype=torch.long) * 31 + 7) % 1000
+    return x, xk, t_emb, t
+
+
+def make_full_rows(oa):
+    """BASELINE configs[1]'s batch with 32 distinct rows, embeddings and timesteps: the reference's outputs for rows 0, 13 and 31 (evaluated as a batch
+    of three: the reference has no cross-row term) of IllNet (t_emb per row), RefNet and ObsNet (timestep per row) at full width, 3x128x256, and of one
+    DRMNet reverse step (DRMNet.p_mean_variance, models/drmnet.py:752-770, reversed_k = 3) on those rows.  Outputs stored at every second pixel."""
+    x, xk, t_emb, t = full_rows_inputs()
+    rows = list(FULL_ROWS)
+    xc = torch.cat([xk, x], dim=1)[rows].contiguous()
+    out = dict(rows=np.asarray(rows), xsum=synth.checksum(x), xksum=synth.checksum(xk), tembsum=synth.checksum(t_emb), t=t)
+    for name, cfg, cls, seed in (("illnet", ou.ILLNET_CFG, oa.UNetModel, synth.SEED_ILLNET), ("refnet", ou.REFNET_CFG, oa.EncoderUNetModel, synth.SEED_REFNET),
+                                 ("obsnet", ou.OBSNET_CFG, oa.UNetModel, synth.SEED_OBSNET)):
+        m = cls(**cfg).eval()
+        load_rule(m, seed)
+        t0 = time.time()
+        with torch.no_grad():
+            y = m(xc, t_emb=t_emb[rows]) if name == "illnet" else m(xc, t[rows])
+        print(f"  {name} rows {rows}: {time.time() - t0:.1f}s  out std {y.std():.4f}")
+        out[name] = y if name == "refnet" else y[:, :, ::2, ::2]
+        del m
+    m = full_drmnet(gamma=0.9, epsilon=0.01, max_timesteps=150)
+    with torch.no_grad():
+        mean, delta, z_out = m.p_mean_variance(xk[rows], [x[rows]], [x[rows]], reversed_k=3)
+    out.update(step_mean=mean[:, :, ::2, ::2], step_z_out=z_out, step_k=3, step_delta=delta)
+    save("full_rows", **out)
+
+
 def make_full_sizes(oa):
     """UNetModel / EncoderUNetModel are fully convolutional (openaimodel.py:731-768): any H, W divisible by 2^(levels-1).
     Full-width outputs at sizes other than the shipped 128x128 / 128x256 (a different ds.size)."""
@@ -1039,6 +1077,7 @@ STEPS = {
     "drmnet_loop_full": lambda oa: make_drmnet_loop(full=True),
     "estimate_chain_full": lambda oa: make_estimate_chain(full=True),
     "full_sizes": lambda oa: make_full_sizes(oa),
+    "full_rows": lambda oa: make_full_rows(oa),
     "obsnet_samplers": lambda oa: make_obsnet_samplers(),
     "sampler_masks": lambda oa: make_sampler_masks(),
     "full": lambda oa: make_full_nets(oa),
