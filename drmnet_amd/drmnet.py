@@ -246,7 +246,7 @@ class DRMNet(nn.Module):
             data = ac.get("probe")
         sigs = (which, ill.__dict__["_auto"]["sig"], ref.__dict__["_auto"]["sig"])
         key = sigs + ("data" if data is not None else "synth",)
-        if key not in ac["done"] and data is None and sigs + ("data",) in ac["done"]:
+        if data is None and sigs + ("data",) in ac["done"]:
             key = sigs + ("data",)  # (measured on the caller's rows before: that record stands)
         if key in ac["done"]:
             ac["report"] = ac["done"][key]

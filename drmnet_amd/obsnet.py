@@ -207,8 +207,8 @@ class LatentDiffusion(DDPM):
             data = ac.get("probe")
         sigs = (unet._active_set, unet.__dict__["_auto"]["sig"])
         key = sigs + ("data" if data is not None else "synth",)
-        if key not in ac["done"] and data is None and sigs + ("data",) in ac["done"]:
-            key = sigs + ("data",)
+        if data is None and sigs + ("data",) in ac["done"]:
+            key = sigs + ("data",)  # (measured on the caller's rows before: that record stands)
         if key in ac["done"]:
             ac["report"] = ac["done"][key]
             return
