@@ -100,11 +100,13 @@ class DDIMSampler(object):
         update kernel of the steps the device table marks (csrc/samplers.hip), so the chain stays one device loop.
         ``mask`` / ``x0`` (ddim.py:175-178): before every step img = q_sample(x0, t) * mask + (1 - mask) * img, on the device (mask_blend_kernel;
         ``mask_noise`` [steps,N,C,H,W] injects q_sample's draws, else Philox).  ``temperature`` (ddim.py:255) scales the step noise: the sigma column
-        of the coefficient table.  Guidance, score correctors, noise_dropout, callbacks and quantisation stay rejected."""
+        of the coefficient table.  ``timesteps`` (ddim.py:156-158): the chain over the first ``subset_end`` entries of the DDIM schedule -- fewer rows of the host coefficient
+        table (``ddim_use_original_steps`` raises here as it does, by AttributeError, in the reference).  Guidance, score correctors, noise_dropout,
+        callbacks and quantisation stay rejected."""
         from . import ops
 
-        if any(v is not None for v in (callback, img_callback, score_corrector, unconditional_conditioning, timesteps)) or quantize_denoised or ddim_use_original_steps:
-            raise NotImplementedError("callbacks / score corrector / classifier-free guidance / quantize / original-step schedules are not on the shipped path")
+        if any(v is not None for v in (callback, img_callback, score_corrector, unconditional_conditioning)) or quantize_denoised:
+            raise NotImplementedError("callbacks / score corrector / classifier-free guidance / quantize are not on the shipped path")
         if noise_dropout != 0.0 or unconditional_guidance_scale != 1.0:
             raise NotImplementedError("noise_dropout / guidance are not on the shipped path")
         if (mask is None) != (x0 is None):
@@ -128,6 +130,16 @@ class DDIMSampler(object):
         ws = self._ws.get(int(L.drm_sampler_workspace_bytes(h, n, hh, ww)), dev)
         ts = np.ascontiguousarray(np.asarray(self.ddim_timesteps, dtype=np.int64))
         coef = np.ascontiguousarray(self.ddim_coef)
+        if ddim_use_original_steps:
+            # (the reference cannot run this either: p_sample_ddim reads self.model.ddim_sigmas_for_original_num_steps, ddim.py:242, which
+            #  make_schedule registers on the SAMPLER, ddim.py:62 -> AttributeError on the first step)
+            raise NotImplementedError("ddim_use_original_steps: unreachable in the reference too (ddim.py:242 reads a buffer the model does not have)")
+        if timesteps is not None:  # ddim.py:156-158: the first subset_end entries of the DDIM schedule
+            n_all = len(ts)
+            subset_end = int(min(timesteps / n_all, 1) * n_all) - 1
+            if subset_end < 1:
+                raise ValueError(f"timesteps = {timesteps} leaves no DDIM step (subset_end = {subset_end})")
+            ts, coef = np.ascontiguousarray(ts[:subset_end]), np.ascontiguousarray(coef[:subset_end])
         if temperature != 1.0:  # noise = sigma_t * randn * temperature (ddim.py:255); dir_xt keeps the un-scaled sigma (its own column)
             coef = coef.copy()
             coef[:, 4] = (torch.from_numpy(coef[:, 4]) * float(temperature)).numpy()

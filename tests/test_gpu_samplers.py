@@ -224,6 +224,28 @@ def test_sampler_mask_x0_temperature_vs_reference_traces(dev, precision):
         s.sample(50, 3, (3, 16, 16), cond, eta=0.0, x_T=x_T, verbose=False, seed=5, unconditional_guidance_scale=2.0, unconditional_conditioning=cond)
 
 
+def test_ddim_timesteps_subset_vs_reference_trace(dev):
+    """[r6] DDIMSampler.ddim_sampling(timesteps=30) (ddim.py:156-158: the first 29 entries of the 50-step schedule) against the reference's trace;
+    ddim_use_original_steps raises here as it does in the reference (recorded in the fixture)."""
+    from drmnet_amd.ddim import DDIMSampler
+
+    g = gold("ddim_variants")
+    m = tiny_obsnet(dev).set_precision("f16x3")
+    cond, x_T, noise = (torch.from_numpy(g[k]).to(dev) for k in ("cond", "x_T", "noise"))
+    s = DDIMSampler(m)
+    s.make_schedule(50, ddim_eta=1.0, verbose=False)
+    x, inter = s.ddim_sampling(cond, tuple(x_T.shape), x_T=x_T, noise=noise, timesteps=30, log_every_t=1, verbose=False)
+    assert len(inter["x_inter"]) - 1 == int(g["subset_n"]) == 29
+    e1, e = rel_l2(inter["x_inter"][1].cpu(), g["subset_first"]), rel_l2(x.cpu(), g["subset_x"])
+    print(f"ddim timesteps=30 (29 steps): first {e1:.2e}, final {e:.2e}")
+    assert e1 < 2e-5 and e < 2e-5
+    assert int(g["orig_runs"]) == 0
+    with pytest.raises(NotImplementedError):
+        s.ddim_sampling(cond, tuple(x_T.shape), x_T=x_T, noise=noise, ddim_use_original_steps=True, verbose=False)
+    with pytest.raises(ValueError):
+        s.ddim_sampling(cond, tuple(x_T.shape), x_T=x_T, noise=noise, timesteps=1, verbose=False)
+
+
 def test_step_dropins_match_reference_named_methods(dev):
     """DRMNet.forward / p_mean_variance and LatentDiffusion.apply_model / p_sample keep the reference's per-step semantics."""
     from oracle import samplers as osamp

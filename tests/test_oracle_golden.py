@@ -243,6 +243,23 @@ def test_sampler_mask_x0_temperature_traces():
         assert rel_l2(imgs[k], g["temp_x"][k]) < 5 * TOL
 
 
+def test_ddim_timesteps_subset_trace():
+    """[r6] DDIMSampler.ddim_sampling(timesteps=30) (ddim.py:156-158): the first int(min(30 / 50, 1) * 50) - 1 = 29 entries of the 50-step schedule, run from
+    index 28 down; the fixture also records that ddim_use_original_steps cannot run in the reference (AttributeError at ddim.py:242)."""
+    g = gold("ddim_variants")
+    assert int(g["subset_n"]) == 29 and int(g["orig_runs"]) == 0
+    Pu, _, _, tu, _ = tiny_nets()
+    S = osamp.ddpm_schedule(1000, 1e-4, 0.09)
+    d = osamp.ddim_schedule(S["alphas_cumprod"], 1000, 50, 1.0)
+    sub = dict(d)
+    for k in ("ddim_timesteps", "ddim_alphas", "ddim_alphas_prev", "ddim_sigmas", "ddim_sqrt_one_minus_alphas"):
+        if k in sub:
+            sub[k] = sub[k][:29]
+    eps_model = lambda xc, t: ou.unet_forward(Pu, tu, xc, timesteps=t)
+    x, xs = osamp.ddim_sample(eps_model, torch.from_numpy(g["cond"]), torch.from_numpy(g["x_T"]), torch.from_numpy(g["noise"]), sub)
+    assert len(xs) == 29 and rel_l2(xs[0], g["subset_first"]) < TOL and rel_l2(x, g["subset_x"]) < 2e-4
+
+
 def full_sampler_inputs():
     """Regenerates the seeded inputs of tests/golden/full_obsnet_sampler_steps.npz (tools/make_golden.py make_full_samplers)."""
     g = gold("full_obsnet_sampler_steps")

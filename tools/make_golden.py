@@ -478,6 +478,44 @@ def make_sampler_masks():
     save("sampler_masks", **out)
 
 
+def make_ddim_variants():
+    """DDIMSampler.ddim_sampling called directly with the schedule argument DDIMSampler.sample never passes (ddim.py:156-158): `timesteps` (a subset of
+    the 50-step DDIM schedule: timesteps = 30 -> its first 29 entries), eta = 1.  Tiny ObsNet, B = 3 @16x16, draws injected."""
+    import ldm.models.diffusion.ddim as refddim
+
+    m, DDIM = tiny_obsnet()
+    B, h, w = 3, 16, 16
+    g = gen(61)
+    cond = synth.synth_refmaps(B, h, w, 98) * 2 - 1
+    x_T = torch.randn((B, 3, h, w), generator=g)
+    noise = torch.randn((50, B, 3, h, w), generator=g)
+    ctr = {"i": 0}
+
+    def noise_like(shape, device, repeat=False):
+        out = noise[ctr["i"]]
+        ctr["i"] += 1
+        return out
+
+    o1 = refddim.noise_like
+    refddim.noise_like = noise_like
+    out = dict(cond=cond, x_T=x_T, noise=noise)
+    try:
+        s = DDIM(m)
+        s.make_schedule(ddim_num_steps=50, ddim_eta=1.0, verbose=False)
+        ctr["i"] = 0
+        x, inter = s.ddim_sampling(cond, (B, 3, h, w), x_T=x_T, timesteps=30, log_every_t=1, verbose=False)
+        out.update(subset_x=x, subset_n=len(inter["x_inter"]) - 1, subset_first=inter["x_inter"][1])
+        try:  # ddim_use_original_steps cannot run in the reference (ddim.py:242 reads a sampler buffer from the model): recorded as such
+            s.ddim_sampling(cond, (B, 3, h, w), x_T=x_T, ddim_use_original_steps=True, timesteps=12, log_every_t=1, verbose=False)
+            out["orig_runs"] = 1
+        except AttributeError:
+            out["orig_runs"] = 0
+    finally:
+        refddim.noise_like = o1
+    print(f"  ddim variants: subset steps {out['subset_n']}, original-steps path runs in the reference: {bool(out['orig_runs'])}")
+    save("ddim_variants", **out)
+
+
 def make_full_samplers():
     """Full-width ObsNet (configs/obsnet/eval_obsnet.yaml, 147.6 M parameters by the synth rule) at the metric shape 3x128x256:
     the first two DDIM steps (eta = 1; ddim.py:206-259 p_sample_ddim at index 49, 48) and the first two ancestral steps
@@ -1080,6 +1118,7 @@ STEPS = {
     "full_rows": lambda oa: make_full_rows(oa),
     "obsnet_samplers": lambda oa: make_obsnet_samplers(),
     "sampler_masks": lambda oa: make_sampler_masks(),
+    "ddim_variants": lambda oa: make_ddim_variants(),
     "full": lambda oa: make_full_nets(oa),
     "full_samplers": lambda oa: make_full_samplers(),
     "transforms": lambda oa: make_transforms(),
