@@ -114,6 +114,34 @@ def test_drmnet_step_batch32_of_distinct_rows(dev, precision):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_drmnet_loop_batch128_forked_row_ranges_distinct_rows(dev, precision):
+    """The north-star's per-GPU batch (1024 / 8 = 128 rows) as the product runs it: drm_drmnet_sample over two reverse steps, each step's rows as two
+    ranges of 64 on forked streams (drm_drmnet_set_batch_parts default) -- here with 128 DISTINCT rows and their own noise draws.  Every 8th row of
+    BOTH ranges, and the rows either side of the range boundary, against the same loop run on that row alone: a row offset lost in the second range
+    (inputs, timestep, z embedding, update, noise) would show there."""
+    from test_gpu_configs34 import full_drmnet
+
+    B, T = 128, 2
+    x = synth.synth_refmaps(B, 128, 256, 4242)
+    g = torch.Generator().manual_seed(4245)
+    n0 = torch.randn(x.shape, generator=g)
+    sn = torch.randn((T,) + tuple(x.shape), generator=g)
+    m = full_drmnet(dev, precision, gamma=0.9, epsilon=0.01, max_timesteps=T)
+    X, N0, SN = x.to(dev), n0.to(dev), sn.to(dev)
+    Lr0, zK, K = m.p_sample_loop(X, [X], [X], verbose=False, noise0=N0, step_noise=SN, early_exit=False)
+    assert torch.isfinite(Lr0).all() and rel_l2(Lr0[64].cpu(), Lr0[0].cpu()) > 1e-2  # (distinct rows on both sides of the boundary)
+    worst = 0.0
+    for r in sorted(set(list(range(0, B, 8)) + [62, 63, 64, 65, 127])):
+        xr = X[r:r + 1].contiguous()
+        one, _, _ = m.p_sample_loop(xr, [xr], [xr], verbose=False, noise0=N0[r:r + 1].contiguous(), step_noise=SN[:, r:r + 1].contiguous(), early_exit=False)
+        worst = max(worst, rel_l2(Lr0[r].cpu(), one[0].cpu()))
+    print(f"DRMNet loop B=128, two forked row ranges, {T} steps ({precision}): worst probed row vs the loop on that row alone {worst:.2e}")
+    assert worst < SELF_TOL[precision]
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_configs2_as_written_bf16_ddim50_graph_replay(dev):
     """BASELINE configs[2]: "DRMNet DDIM 50-step, bf16, hipGraph-captured step" -- ObsNet's DDIM-50 chain (the reference's only DDIM schedule) at
     B = 32 @3x128x256 on bf16 operands: the replayed chain is the eager chain bit for bit, and its final state sits within the bf16 tolerance (3e-2,
