@@ -25,7 +25,7 @@ SYMBOLS = [
     "drm_unet_workspace_bytes", "drm_unet_forward",
     "drm_linear_forward", "drm_timestep_embedding", "drm_op_norm_act_conv", "drm_op_resblock", "drm_op_attention_block",
     "drm_drmnet_create", "drm_drmnet_destroy", "drm_drmnet_workspace_bytes", "drm_drmnet_set_batch_parts", "drm_drmnet_set_batch_part_min", "drm_drmnet_step", "drm_drmnet_sample",
-    "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddim_sample_logged", "drm_ddpm_sample", "drm_ddim_sample_masked", "drm_ddpm_sample_masked", "drm_randn",
+    "drm_sampler_workspace_bytes", "drm_ddim_sample", "drm_ddim_sample_logged", "drm_ddpm_sample", "drm_ddim_sample_ex", "drm_ddpm_sample_ex", "drm_randn",
     "drm_profile_enable", "drm_profile_reset", "drm_profile_collect", "drm_unet_set_precision", "drm_set_op_precision",
     "drm_refmap_workspace_bytes", "drm_refmap_mask_make", "drm_erode_mask",
     "drm_unet_load_params_set", "drm_unet_use_set", "drm_set_graph_replay", "drm_graph_launches",
@@ -43,6 +43,10 @@ class UNetDesc(C.Structure):
 
 class MaskBlend(C.Structure):  # drm_mask_blend
     _fields_ = [("mask", C.c_void_p), ("mask_channels", C.c_int32), ("x0", C.c_void_p), ("qcoef", C.POINTER(C.c_float)), ("qnoise", C.c_void_p), ("when", C.c_int32)]
+
+
+class SamplerOptions(C.Structure):  # drm_sampler_options
+    _fields_ = [("blend", C.POINTER(MaskBlend)), ("uncond", C.c_void_p), ("guidance_scale", C.c_float), ("noise_dropout", C.c_float), ("dropout_keep", C.c_void_p)]
 
 
 class DrmnetCfg(C.Structure):
@@ -76,6 +80,30 @@ def make_mask_blend(mask, x0, qcoef, qnoise, when: int, img_shape):
     b.qnoise = None if qn is None else qn.data_ptr()
     b.when = int(when)
     return b, (mask, x0, qc, qn)
+
+
+def make_sampler_options(img_shape, steps, blend=None, uncond=None, guidance_scale=1.0, noise_dropout=0.0, dropout_keep=None):
+    """drm_sampler_options for a chain on `img_shape`: blend = (struct, keep-alive) of make_mask_blend or None; uncond [N,C,H,W]; dropout_keep
+    [steps,N,C,H,W] 0 / 1 or None.  Returns (struct, keep-alive tuple)."""
+    o = SamplerOptions()
+    keep = [blend]
+    if blend is not None:
+        o.blend = C.pointer(blend[0])
+    if uncond is not None:
+        u = require_gpu_tensor(uncond, "unconditional_conditioning").float().contiguous()
+        if tuple(u.shape) != tuple(img_shape):
+            raise RuntimeError(f"unconditional_conditioning must be {tuple(img_shape)}")
+        o.uncond = u.data_ptr()
+        keep.append(u)
+    o.guidance_scale = float(guidance_scale)
+    o.noise_dropout = float(noise_dropout)
+    if dropout_keep is not None:
+        k = require_gpu_tensor(dropout_keep, "dropout_keep").float().contiguous()
+        if tuple(k.shape) != (int(steps),) + tuple(img_shape):
+            raise RuntimeError(f"dropout_keep must be [steps={steps}, N, C, H, W]")
+        o.dropout_keep = k.data_ptr()
+        keep.append(k)
+    return o, tuple(keep)
 
 
 _lib: Optional[C.CDLL] = None
@@ -127,9 +155,9 @@ def lib() -> C.CDLL:
     L.drm_ddim_sample_logged.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, fp, fp, i32, C.POINTER(C.c_int32),
                                          i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_ddpm_sample.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, i32, i32, i32, vp, C.c_size_t, vp]
-    L.drm_ddim_sample_masked.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, C.POINTER(MaskBlend), i32, fp, fp, i32,
-                                         C.POINTER(C.c_int32), i32, i32, i32, vp, C.c_size_t, vp]
-    L.drm_ddpm_sample_masked.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, C.POINTER(MaskBlend), i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_ddim_sample_ex.argtypes = [vp, fp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, C.POINTER(SamplerOptions), i32, fp, fp, i32,
+                                     C.POINTER(C.c_int32), i32, i32, i32, vp, C.c_size_t, vp]
+    L.drm_ddpm_sample_ex.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_float), i32, i32, fp, C.c_uint64, C.POINTER(SamplerOptions), i32, i32, i32, vp, C.c_size_t, vp]
     L.drm_randn.argtypes = [fp, C.c_size_t, C.c_uint64, C.c_uint64, vp]
     u8p = vp
     L.drm_refmap_workspace_bytes.argtypes = [C.c_int64, i32, C.c_float]

@@ -444,32 +444,37 @@ static MaskBlend to_blend(const drm_mask_blend* b) {
   return m;
 }
 
-int drm_ddim_sample_masked(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
-                           const float* noise, uint64_t seed, const drm_mask_blend* blend, int log_every_t, float* log_x, float* log_pred_x0, int log_slots,
-                           int32_t* n_logged, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+int drm_ddim_sample_ex(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
+                       const float* noise, uint64_t seed, const drm_sampler_options* opt, int log_every_t, float* log_x, float* log_pred_x0, int log_slots,
+                       int32_t* n_logged, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(net && x && cond && blend, "null argument");
+    DRM_REQUIRE(net && x && cond && opt, "null argument");
     DRM_REQUIRE(log_every_t <= 0 || (log_x && log_pred_x0 && log_slots > 0), "ddim intermediates: both log buffers and their slot count");
     Arena ar;
     DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
-    const MaskBlend mb = to_blend(blend);
+    MaskBlend mb;
+    if (opt->blend) mb = to_blend(opt->blend);
     int logged = 0;
     const int rc = ddim_sample(&net->net, x, cond, timesteps, coef, S, num_steps, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream),
-                               log_every_t > 0 ? log_every_t : 0, log_every_t > 0 ? log_x : nullptr, log_every_t > 0 ? log_pred_x0 : nullptr, log_slots, &logged, &mb);
+                               log_every_t > 0 ? log_every_t : 0, log_every_t > 0 ? log_x : nullptr, log_every_t > 0 ? log_pred_x0 : nullptr, log_slots, &logged,
+                               opt->blend ? &mb : nullptr, opt->uncond, opt->guidance_scale, opt->noise_dropout, opt->dropout_keep);
     if (n_logged) *n_logged = logged;
     return rc;
   });
 }
 
-int drm_ddpm_sample_masked(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
-                           const float* noise, uint64_t seed, const drm_mask_blend* blend, int N, int H, int W, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+int drm_ddpm_sample_ex(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
+                       const float* noise, uint64_t seed, const drm_sampler_options* opt, int N, int H, int W, void* workspace, size_t workspace_bytes,
+                       void* stream) {
   return guarded([&]() -> int {
-    DRM_REQUIRE(net && x && cond && blend, "null argument");
+    DRM_REQUIRE(net && x && cond && opt, "null argument");
+    DRM_REQUIRE(opt->uncond == nullptr, "drm_ddpm_sample_ex: classifier-free guidance exists on the DDIM chain only (ddim.py:225-232; ddpm.py p_sample has none)");
     Arena ar;
     DRM_TRY(make_arena(ar, workspace, workspace_bytes, sampler_workspace_bytes(&net->net, N, H, W)));
-    const MaskBlend mb = to_blend(blend);
-    return ddpm_sample(&net->net, x, pred_x0, cond, coef, T_start, clip_denoised, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream), &mb);
+    MaskBlend mb;
+    if (opt->blend) mb = to_blend(opt->blend);
+    return ddpm_sample(&net->net, x, pred_x0, cond, coef, T_start, clip_denoised, noise, seed, N, H, W, ar, static_cast<hipStream_t>(stream), opt->blend ? &mb : nullptr,
+                       opt->noise_dropout, opt->dropout_keep);
   });
 }
 

@@ -66,8 +66,9 @@ struct MaskBlend {
 // log_every_t > 0 with log_x / log_pred ([log_slots][N,3,H,W] each): the reference's intermediates (ddim.py:198-200), *n_logged = slots written
 int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
                 uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s, int log_every_t = 0, float* log_x = nullptr, float* log_pred = nullptr,
-                int log_slots = 0, int* n_logged = nullptr, const MaskBlend* blend = nullptr);
+                int log_slots = 0, int* n_logged = nullptr, const MaskBlend* blend = nullptr, const float* uncond = nullptr, float guidance_scale = 1.0f,
+                float drop_p = 0.f, const float* drop_keep = nullptr);
 int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip, const float* noise,
-                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s, const MaskBlend* blend = nullptr);
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t s, const MaskBlend* blend = nullptr, float drop_p = 0.f, const float* drop_keep = nullptr);
 
 }  // namespace drm

@@ -51,6 +51,20 @@ __device__ __forceinline__ float philox_normal1(uint64_t seed, uint64_t elem) {
   return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
 }
 
+// one uniform in (0, 1) per element (dropout masks): the same counter-based stream, without the Box-Muller step
+__device__ __forceinline__ float philox_uniform1(uint64_t seed, uint64_t elem) {
+  const uint64_t ctr = elem >> 2;
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return ((float)c[elem & 3] + 0.5f) * 2.3283064365386963e-10f;
+}
+
 __global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = philox_normal1(seed, offset + i);
@@ -158,9 +172,17 @@ __global__ void step_advance_kernel(int* counter) { *counter += 1; }
 
 // pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);  x = sqrt(a_prev) pred_x0 + sqrt(1-a_prev-s^2) e + s * noise   (ddim.py:249-258)
 // log_x / log_pred (optional): the reference's `intermediates` (ddim.py:171-204): slots of n floats, written by the steps the table marks
+// noise_dropout (ddim.py:256-257, ddpm.py:1158-1159: F.dropout on the step noise): an element is kept with probability 1 - p and scaled by 1 / (1 - p);
+// keep: [steps][n] 0 / 1 masks (parity runs) or null -> Philox under a key of its own
+__device__ __forceinline__ float dropout_factor(float p, const float* __restrict__ keep, int j, size_t n, size_t i, uint64_t seed) {
+  if (p <= 0.f) return 1.0f;
+  const bool k = keep ? keep[(size_t)j * n + i] != 0.f : philox_uniform1(seed ^ 0xD1B54A32D192ED03ull, (uint64_t)(j + 1) * n + i) >= p;
+  return k ? 1.0f / (1.0f - p) : 0.f;
+}
+
 __global__ void ddim_update_kernel(float* __restrict__ x, const float* __restrict__ e, const float* __restrict__ noise, size_t n,
                                    const float* __restrict__ tab, const int* __restrict__ counter, uint64_t seed, float* __restrict__ log_x,
-                                   float* __restrict__ log_pred) {
+                                   float* __restrict__ log_pred, float drop_p, const float* __restrict__ drop_keep) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int j = *counter;
@@ -169,7 +191,7 @@ __global__ void ddim_update_kernel(float* __restrict__ x, const float* __restric
   const float xv = x[i], ev = e[i];
   const float pred = (xv - s1m * ev) / sa;
   float nz = 0.f;
-  if (sig != 0.f) nz = noise ? noise[(size_t)j * n + i] : philox_normal1(seed, (uint64_t)(j + 1) * n + i);
+  if (sig != 0.f) nz = (noise ? noise[(size_t)j * n + i] : philox_normal1(seed, (uint64_t)(j + 1) * n + i)) * dropout_factor(drop_p, drop_keep, j, n, i, seed);
   const float xn = sap * pred + sdir * ev + sig * nz;
   x[i] = xn;
   const int slot = (int)c[6];  // (row element 7)
@@ -182,7 +204,7 @@ __global__ void ddim_update_kernel(float* __restrict__ x, const float* __restric
 // x_recon = c0 x - c1 e; mean = c2 x_recon + c3 x; x = mean + [t>0] c4 noise   (ddpm.py:233-246,1156-1167)
 __global__ void ddpm_update_kernel(float* __restrict__ x, float* __restrict__ pred_x0, const float* __restrict__ e,
                                    const float* __restrict__ noise, size_t n, const float* __restrict__ tab, const int* __restrict__ counter,
-                                   int clip, uint64_t seed) {
+                                   int clip, uint64_t seed, float drop_p, const float* __restrict__ drop_keep) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int j = *counter;
@@ -193,11 +215,21 @@ __global__ void ddpm_update_kernel(float* __restrict__ x, float* __restrict__ pr
   const float mean = c[2] * xr + c[3] * xv;
   float v = mean;
   if (c[5] != 0.f) {
-    const float nz = noise ? noise[(size_t)j * n + i] : philox_normal1(seed, (uint64_t)(j + 1) * n + i);
+    const float nz = (noise ? noise[(size_t)j * n + i] : philox_normal1(seed, (uint64_t)(j + 1) * n + i)) * dropout_factor(drop_p, drop_keep, j, n, i, seed);
     v += c[4] * nz;
   }
   x[i] = v;
   if (pred_x0) pred_x0[i] = xr;
+}
+
+// classifier-free guidance (ddim.py:225-232): e = e_uncond + scale * (e_cond - e_uncond); the reference evaluates both in one batch of 2 N rows
+// (rows do not interact: two forwards give the same numbers)
+__global__ void cfg_combine_kernel(float* __restrict__ e, const float* __restrict__ e_uncond, float scale, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float u = e_uncond[i];
+    e[i] = u + scale * (e[i] - u);
+  }
 }
 
 // Known-region blending of the samplers' `mask` / `x0` arguments (inpainting-style conditioning):
@@ -445,7 +477,8 @@ size_t sampler_workspace_bytes(UNet* net, int N, int H, int W) {
   const size_t chw = (size_t)net->desc.out_channels * H * W;
   // U-Net arena + eps [N,C,H,W] + timesteps [N] + the per-step scalar table (<= 4096 steps) and its counter
   // (+ the mask-blend (a, b) pair per step, same bound)
-  return a.peak + ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + ((size_t)MAX_TABLE_STEPS * (STEP_ROW + 2) * sizeof(float) + 512) + 1024;
+  // (+ a second eps buffer: the unconditional branch of classifier-free guidance)
+  return a.peak + 2 * ((size_t)N * chw * sizeof(float) + 256) + ((size_t)N * sizeof(float) + 256) + ((size_t)MAX_TABLE_STEPS * (STEP_ROW + 2) * sizeof(float) + 512) + 1024;
 }
 
 // Runs `steps` identical-launch steps: the first eagerly (it also sizes caches and sets per-kernel attributes), the second under
@@ -574,7 +607,7 @@ static int upload_blend_table(const MaskBlend* blend, int steps, float* qtab, hi
 
 int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps, const float* noise,
                 uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller, int log_every_t, float* log_x, float* log_pred, int log_slots,
-                int* n_logged, const MaskBlend* blend) {
+                int* n_logged, const MaskBlend* blend, const float* uncond, float guidance_scale, float drop_p, const float* drop_keep) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddim needs a UNetModel");
   DRM_REQUIRE(S >= 1 && timesteps && coef, "ddim schedule");
   DRM_REQUIRE(S <= MAX_TABLE_STEPS, "ddim: at most " + std::to_string(MAX_TABLE_STEPS) + " steps (the workspace budgets the step table for that many)");
@@ -588,7 +621,9 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
   float* tab = ar.alloc<float>((size_t)steps * STEP_ROW);
   int* counter = ar.alloc<int>(1);
   float* qtab = blend ? ar.alloc<float>((size_t)steps * 2) : nullptr;
+  float* e_u = uncond ? ar.alloc<float>(n) : nullptr;
   if (ar.failed) { set_error("ddim: workspace too small"); return DRM_ERR_WORKSPACE; }
+  DRM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "noise_dropout: 0 <= p < 1");
   DRM_REQUIRE(!blend || blend->mask_channels == 1 || blend->mask_channels == Cx, "mask blending: the mask has 1 or out_channels channels");
   std::vector<float> rows((size_t)steps * STEP_ROW, 0.f);
   int logged = 0;
@@ -620,7 +655,13 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
     if (blend && blend->when == 0) DRM_TRY(blend_now());
     ar.release(mark);
     DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
-    hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, e, noise, n, tab, counter, seed, log_x, log_pred);
+    if (uncond) {
+      ar.release(mark);
+      DRM_TRY(net->forward(x, Cx, uncond, Cc, nullptr, nullptr, nullptr, tf, e_u, N, H, W, ar, s));
+      hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, e, e_u, guidance_scale, n);
+      DRM_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(ddim_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, e, noise, n, tab, counter, seed, log_x, log_pred, drop_p, drop_keep);
     DRM_HIP_CHECK(hipGetLastError());
     if (blend && blend->when == 1) DRM_TRY(blend_now());
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);
@@ -630,7 +671,7 @@ int ddim_sample(UNet* net, float* x, const float* cond, const int64_t* timesteps
 }
 
 int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip, const float* noise,
-                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller, const MaskBlend* blend) {
+                uint64_t seed, int N, int H, int W, Arena& ar, hipStream_t caller, const MaskBlend* blend, float drop_p, const float* drop_keep) {
   DRM_REQUIRE(net && net->desc.kind == 0, "ddpm needs a UNetModel");
   DRM_REQUIRE(T_start >= 1 && coef, "ddpm schedule");
   DRM_REQUIRE(T_start <= MAX_TABLE_STEPS, "ddpm: at most " + std::to_string(MAX_TABLE_STEPS) + " steps (the workspace budgets the step table for that many)");
@@ -668,7 +709,7 @@ int ddpm_sample(UNet* net, float* x, float* pred_x0, const float* cond, const fl
     if (blend && blend->when == 0) DRM_TRY(blend_now());
     ar.release(mark);
     DRM_TRY(net->forward(x, Cx, cond, Cc, nullptr, nullptr, nullptr, tf, e, N, H, W, ar, s));
-    hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, pred_x0, e, noise, n, tab, counter, clip, seed);
+    hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, pred_x0, e, noise, n, tab, counter, clip, seed, drop_p, drop_keep);
     DRM_HIP_CHECK(hipGetLastError());
     if (blend && blend->when == 1) DRM_TRY(blend_now());
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, counter);

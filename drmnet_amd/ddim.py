@@ -81,34 +81,38 @@ class DDIMSampler(object):
         if conditioning is not None and not isinstance(conditioning, dict):
             if conditioning.shape[0] != batch_size:
                 print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
-        if any(v is not None for v in (callback, img_callback, score_corrector, unconditional_conditioning)) or quantize_x0:
-            raise NotImplementedError("callbacks / score corrector / classifier-free guidance / quantize are not on the shipped path")
-        if noise_dropout != 0.0 or unconditional_guidance_scale != 1.0:
-            raise NotImplementedError("noise_dropout / guidance are not on the shipped path")
+        if any(v is not None for v in (callback, img_callback, score_corrector)) or quantize_x0:
+            raise NotImplementedError("callbacks / score corrector / quantize: host hooks of the reference with no device form here")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         size = (batch_size, *shape)
         return self.ddim_sampling(conditioning, size, x_T=x_T, log_every_t=log_every_t, verbose=verbose, noise=noise, seed=seed, num_steps=num_steps,
-                                  mask=mask, x0=x0, temperature=temperature, mask_noise=kwargs.get("mask_noise"))
+                                  mask=mask, x0=x0, temperature=temperature, mask_noise=kwargs.get("mask_noise"), noise_dropout=noise_dropout,
+                                  dropout_keep=kwargs.get("dropout_keep"), unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning)
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, log_every_t=100, verbose=True, noise=None, seed=None, num_steps=None, mask=None, x0=None,
                       temperature=1.0, mask_noise=None, noise_dropout=0.0, callback=None, img_callback=None, quantize_denoised=False, score_corrector=None,
                       corrector_kwargs=None, unconditional_guidance_scale=1.0, unconditional_conditioning=None, ddim_use_original_steps=False,
-                      timesteps=None):
+                      timesteps=None, dropout_keep=None):
         """ddim.py:128-204 -> (final x, intermediates).  ``intermediates`` is the reference's record (ddim.py:171-204): "x_inter" and "pred_x0" start
         with x_T and receive (img, pred_x0) after the step of ``index`` whenever index % log_every_t == 0 or at the first step -- written by the
         update kernel of the steps the device table marks (csrc/samplers.hip), so the chain stays one device loop.
         ``mask`` / ``x0`` (ddim.py:175-178): before every step img = q_sample(x0, t) * mask + (1 - mask) * img, on the device (mask_blend_kernel;
         ``mask_noise`` [steps,N,C,H,W] injects q_sample's draws, else Philox).  ``temperature`` (ddim.py:255) scales the step noise: the sigma column
         of the coefficient table.  ``timesteps`` (ddim.py:156-158): the chain over the first ``subset_end`` entries of the DDIM schedule -- fewer rows of the host coefficient
-        table (``ddim_use_original_steps`` raises here as it does, by AttributeError, in the reference).  Guidance, score correctors, noise_dropout,
-        callbacks and quantisation stay rejected."""
+        table (``ddim_use_original_steps`` raises here as it does, by AttributeError, in the reference).  ``unconditional_conditioning`` +
+        ``unconditional_guidance_scale`` (ddim.py:225-232): a second forward per step on the unconditional conditioning, e = e_u + s (e_c - e_u).
+        ``noise_dropout`` (ddim.py:256-257): F.dropout on the step noise (``dropout_keep`` [steps,N,C,H,W] injects the 0 / 1 masks, else Philox).
+        Score correctors, callbacks and quantisation are host hooks with no device form: rejected."""
         from . import ops
 
-        if any(v is not None for v in (callback, img_callback, score_corrector, unconditional_conditioning)) or quantize_denoised:
-            raise NotImplementedError("callbacks / score corrector / classifier-free guidance / quantize are not on the shipped path")
-        if noise_dropout != 0.0 or unconditional_guidance_scale != 1.0:
-            raise NotImplementedError("noise_dropout / guidance are not on the shipped path")
+        if any(v is not None for v in (callback, img_callback, score_corrector)) or quantize_denoised:
+            raise NotImplementedError("callbacks / score corrector / quantize: host hooks of the reference with no device form here")
+        if not 0.0 <= noise_dropout < 1.0:
+            raise ValueError("noise_dropout: 0 <= p < 1")
+        # classifier-free guidance (ddim.py:225-232): only with an unconditional conditioning AND a scale != 1, as the reference decides
+        guided = unconditional_conditioning is not None and unconditional_guidance_scale != 1.0
         if (mask is None) != (x0 is None):
             raise ValueError("mask and x0 go together (ddim.py:176)")
 
@@ -156,15 +160,21 @@ class DDIMSampler(object):
         slots = sum(1 for j in range(steps) if log_every_t > 0 and ((S - 1 - j) % log_every_t == 0 or j == 0))
         inter = {"x_inter": [x_start], "pred_x0": [x_start]}
         with torch.cuda.device(dev):
-            if blend is not None:
+            if blend is not None or guided or noise_dropout > 0.0:
+                uc = None
+                if guided:
+                    uc = unconditional_conditioning[0] if isinstance(unconditional_conditioning, (list, tuple)) else unconditional_conditioning
+                opt, keep_o = _lib.make_sampler_options(tuple(img.shape), steps, blend=None if blend is None else (blend, keep), uncond=uc,
+                                                        guidance_scale=unconditional_guidance_scale, noise_dropout=noise_dropout, dropout_keep=dropout_keep)
                 log_x = torch.empty((max(slots, 1),) + tuple(img.shape), dtype=torch.float32, device=dev)
                 log_p = torch.empty_like(log_x)
                 n_logged = C.c_int32(0)
-                _lib.check(L.drm_ddim_sample_masked(h, img.data_ptr(), c.data_ptr(), ts.ctypes.data_as(C.POINTER(C.c_int64)),
-                                                    coef.ctypes.data_as(C.POINTER(C.c_float)), S, int(num_steps or 0), _lib.ptr(noise), seed, C.byref(blend),
-                                                    log_every_t if slots else 0, log_x.data_ptr(), log_p.data_ptr(), slots, C.byref(n_logged), n, hh, ww,
-                                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
-                torch.cuda.current_stream(dev).synchronize()  # (the blend's tensors stay alive until the chain has run)
+                _lib.check(L.drm_ddim_sample_ex(h, img.data_ptr(), c.data_ptr(), ts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                coef.ctypes.data_as(C.POINTER(C.c_float)), S, int(num_steps or 0), _lib.ptr(noise), seed, C.byref(opt),
+                                                log_every_t if slots else 0, log_x.data_ptr(), log_p.data_ptr(), slots, C.byref(n_logged), n, hh, ww,
+                                                ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+                torch.cuda.current_stream(dev).synchronize()  # (the options' tensors stay alive until the chain has run)
+                del keep_o
                 inter["x_inter"] += [log_x[k] for k in range(n_logged.value)]
                 inter["pred_x0"] += [log_p[k] for k in range(n_logged.value)]
             elif slots == 0:

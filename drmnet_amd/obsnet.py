@@ -300,11 +300,12 @@ class LatentDiffusion(DDPM):
 
     @torch.no_grad()
     def _ddpm_loop(self, cond, shape, x_T=None, timesteps=None, start_T=None, noise=None, seed=None, mask=None, x0=None, mask_noise=None, blend_when=1,
-                   temperature=1.0):
+                   temperature=1.0, noise_dropout=0.0, dropout_keep=None):
         """The ancestral chain on the device (drm_ddpm_sample).  mask / x0: the known-region blending of the reference's two loops --
         ``blend_when`` 1 = LatentDiffusion.p_sample_loop (after p_sample, q_sample(x0, t): ddpm.py:1300-1302), 0 = ObsNetDiffusion.p_sample_loop (before
         p_sample, x0 itself at t == 0, else q_sample(x0, t - 1): models/obsnet.py:545-547); ``mask_noise`` [T,N,C,H,W] injects q_sample's draws.
-        ``temperature`` scales the step noise (ddpm.py:1157: the exp(0.5 logvar) column)."""
+        ``temperature`` scales the step noise (ddpm.py:1157: the exp(0.5 logvar) column); ``noise_dropout`` is p_sample's F.dropout on it (ddpm.py:1158-1159;
+        ``dropout_keep`` [T,N,C,H,W] injects the 0 / 1 masks).  (The reference's p_sample_loop passes neither to p_sample: knobs of p_sample itself.)"""
         if (mask is None) != (x0 is None):
             raise ValueError("mask and x0 go together (ddpm.py:1286-1288)")
         dev = self.betas.device
@@ -332,22 +333,27 @@ class LatentDiffusion(DDPM):
         if temperature != 1.0:
             coef = coef.copy()
             coef[:, 4] = (torch.from_numpy(coef[:, 4]) * float(temperature)).numpy()
-        if mask is not None:
-            sa = self.sqrt_alphas_cumprod.detach().cpu().float().numpy()
-            s1 = self.sqrt_one_minus_alphas_cumprod.detach().cpu().float().numpy()
-            q = np.zeros((T, 2), dtype=np.float32)
-            for j in range(T):
-                t = T - 1 - j
-                if blend_when == 1:
-                    q[j] = (sa[t], s1[t])
-                else:
-                    q[j] = (1.0, 0.0) if t == 0 else (sa[t - 1], s1[t - 1])
-            blend, keep = _lib.make_mask_blend(mask, x0, q, mask_noise, blend_when, tuple(img.shape))
+        if not 0.0 <= noise_dropout < 1.0:
+            raise ValueError("noise_dropout: 0 <= p < 1")
+        if mask is not None or noise_dropout > 0.0:
+            blend = None
+            if mask is not None:
+                sa = self.sqrt_alphas_cumprod.detach().cpu().float().numpy()
+                s1 = self.sqrt_one_minus_alphas_cumprod.detach().cpu().float().numpy()
+                q = np.zeros((T, 2), dtype=np.float32)
+                for j in range(T):
+                    t = T - 1 - j
+                    if blend_when == 1:
+                        q[j] = (sa[t], s1[t])
+                    else:
+                        q[j] = (1.0, 0.0) if t == 0 else (sa[t - 1], s1[t - 1])
+                blend = _lib.make_mask_blend(mask, x0, q, mask_noise, blend_when, tuple(img.shape))
+            opt, keep = _lib.make_sampler_options(tuple(img.shape), T, blend=blend, noise_dropout=noise_dropout, dropout_keep=dropout_keep)
             with torch.cuda.device(dev):
-                _lib.check(L.drm_ddpm_sample_masked(h, img.data_ptr(), pred_x0.data_ptr(), c.data_ptr(), coef.ctypes.data_as(C.POINTER(C.c_float)), T,
-                                                    int(bool(self.clip_denoised)), _lib.ptr(noise), seed, C.byref(blend), n, hh, ww, ws.data_ptr(), ws.numel(),
-                                                    _lib.stream_ptr(dev)))
-            torch.cuda.current_stream(dev).synchronize()  # (the blend's tensors stay alive until the chain has run)
+                _lib.check(L.drm_ddpm_sample_ex(h, img.data_ptr(), pred_x0.data_ptr(), c.data_ptr(), coef.ctypes.data_as(C.POINTER(C.c_float)), T,
+                                                int(bool(self.clip_denoised)), _lib.ptr(noise), seed, C.byref(opt), n, hh, ww, ws.data_ptr(), ws.numel(),
+                                                _lib.stream_ptr(dev)))
+            torch.cuda.current_stream(dev).synchronize()  # (the options' tensors stay alive until the chain has run)
             del keep
             return img, pred_x0
         with torch.cuda.device(dev):
@@ -359,11 +365,11 @@ class LatentDiffusion(DDPM):
     @torch.no_grad()
     def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None,
                       quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, noise=None, seed=None,
-                      mask_noise=None, temperature=1.0):
+                      mask_noise=None, temperature=1.0, noise_dropout=0.0, dropout_keep=None):
         """ddpm.py:1253-1313 -> final img.  (intermediates: only the endpoints are kept; the loop runs on the device.)  mask / x0: ddpm.py:1300-1302."""
         if callback is not None or img_callback is not None or quantize_denoised:
             raise NotImplementedError("callbacks / quantize are not on the shipped path")
-        img, _ = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed, mask, x0, mask_noise, 1, temperature)
+        img, _ = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed, mask, x0, mask_noise, 1, temperature, noise_dropout, dropout_keep)
         if return_intermediates:
             return img, [img]
         return img
@@ -400,12 +406,12 @@ class ObsNetDiffusion(LatentDiffusion):
     @torch.no_grad()
     def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None,
                       quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None, noise=None, seed=None,
-                      mask_noise=None, temperature=1.0):
+                      mask_noise=None, temperature=1.0, noise_dropout=0.0, dropout_keep=None):
         """models/obsnet.py:500-564: like LatentDiffusion.p_sample_loop but returns pred_x0 of the LAST step; mask / x0 blend BEFORE p_sample
         (x0 itself at t == 0, else q_sample(x0, t - 1): models/obsnet.py:545-547)."""
         if callback is not None or img_callback is not None or quantize_denoised:
             raise NotImplementedError("callbacks / quantize are not on the shipped path")
-        img, pred_x0 = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed, mask, x0, mask_noise, 0, temperature)
+        img, pred_x0 = self._ddpm_loop(cond, shape, x_T, timesteps, start_T, noise, seed, mask, x0, mask_noise, 0, temperature, noise_dropout, dropout_keep)
         if return_intermediates:
             return pred_x0, {"x_inter": [img], "pred_x0": [pred_x0]}
         return pred_x0

@@ -213,7 +213,8 @@ int drm_ddpm_sample(drm_unet* net, float* x, float* pred_x0, const float* cond, 
  *   DDIMSampler.ddim_sampling      ldm/models/diffusion/ddim.py:175-178   before the step's forward, at the step's t            -> when = 0
  *   ObsNetDiffusion.p_sample_loop  models/obsnet.py:545-547               before p_sample: x0 itself at t == 0, else t - 1       -> when = 0
  *   LatentDiffusion.p_sample_loop  ldm/models/diffusion/ddpm.py:1300-1302 after p_sample, at the step's t                       -> when = 1
- * (`temperature` of p_sample_ddim / p_sample, ddim.py:255 / ddpm.py:1157, needs no entry point: it scales the sigma column of `coef`.) */
+ * (`temperature` of p_sample_ddim / p_sample, ddim.py:255 / ddpm.py:1157, needs no entry point: it scales the sigma column of `coef`.)  Passed through
+ * drm_sampler_options below. */
 typedef struct drm_mask_blend {
   const float* mask;   /* [N, mask_channels, H, W], device */
   int mask_channels;   /* 1 (broadcast over the channels) or 3 */
@@ -223,14 +224,31 @@ typedef struct drm_mask_blend {
   int when;            /* 0 = before the step's network forward, 1 = after its update */
 } drm_mask_blend;
 
-/* drm_ddim_sample_logged / drm_ddpm_sample with the blending above (log_every_t <= 0: no intermediates).  Graph replay applies unchanged (the
- * pairs live in a device table read through the step counter). */
-int drm_ddim_sample_masked(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
-                           const float* noise, uint64_t seed, const drm_mask_blend* blend, int log_every_t, float* log_x, float* log_pred_x0, int log_slots,
-                           int32_t* n_logged, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
-int drm_ddpm_sample_masked(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
-                           const float* noise, uint64_t seed, const drm_mask_blend* blend, int N, int H, int W, void* workspace, size_t workspace_bytes,
-                           void* stream);
+/* The remaining per-step options of the reference's samplers, in one struct (zero-initialise; every member optional):
+ *   blend          mask / x0 (above)
+ *   uncond         DDIM only -- classifier-free guidance (p_sample_ddim, ldm/models/diffusion/ddim.py:225-232): the unconditional conditioning
+ *                  [N,3,H,W]; every step evaluates the network on it as well and uses e = e_uncond + guidance_scale * (e_cond - e_uncond).  (The
+ *                  reference batches both evaluations as 2 N rows; rows do not interact.)
+ *   noise_dropout  F.dropout on the step noise (ddim.py:256-257, ddpm.py:1158-1159): an element is kept with probability 1 - p and scaled by
+ *                  1 / (1 - p); dropout_keep [steps][N,3,H,W] holds 0 / 1 keep masks (parity runs), NULL draws them from Philox(seed) under a key of
+ *                  its own.
+ * Not offered: score correctors, quantize_denoised, callbacks (host hooks of the reference with no device meaning here). */
+typedef struct drm_sampler_options {
+  const drm_mask_blend* blend;
+  const float* uncond;
+  float guidance_scale;
+  float noise_dropout;
+  const float* dropout_keep;
+} drm_sampler_options;
+
+/* drm_ddim_sample_logged / drm_ddpm_sample with the options above (log_every_t <= 0: no intermediates).  Graph replay applies unchanged (every
+ * per-step quantity lives in a device table read through the step counter). */
+int drm_ddim_sample_ex(drm_unet* net, float* x, const float* cond, const int64_t* timesteps, const float* coef, int S, int num_steps,
+                       const float* noise, uint64_t seed, const drm_sampler_options* opt, int log_every_t, float* log_x, float* log_pred_x0, int log_slots,
+                       int32_t* n_logged, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+int drm_ddpm_sample_ex(drm_unet* net, float* x, float* pred_x0, const float* cond, const float* coef, int T_start, int clip_denoised,
+                       const float* noise, uint64_t seed, const drm_sampler_options* opt, int N, int H, int W, void* workspace, size_t workspace_bytes,
+                       void* stream);
 
 size_t drm_sampler_workspace_bytes(const drm_unet* net, int N, int H, int W);
 

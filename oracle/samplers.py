@@ -113,11 +113,16 @@ def ddim_sample(
     q_noise: Optional[Sequence[torch.Tensor]] = None,
     q_coef: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
     temperature: float = 1.0,
+    uncond: Optional[torch.Tensor] = None,
+    guidance_scale: float = 1.0,
+    noise_dropout: float = 0.0,
+    dropout_keep: Optional[Sequence[torch.Tensor]] = None,
 ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """ddim.py:171-204 + :206-259.  eps_model(xc, t) with xc = cat([x, cond], 1)
     (DiffusionWrapper concat branch, ddpm.py:1527-1529).  Returns final x (not pred_x0).
     mask / x0 (ddim.py:175-178): before every step x = q_sample(x0, t) * mask + (1 - mask) * x with q_sample = sqrt_alphas_cumprod[t] x0 +
-    sqrt_one_minus_alphas_cumprod[t] q_noise[j] (ddpm.py:1052-1058; q_coef = those two fp32 tables); temperature scales the step noise (ddim.py:255)."""
+    sqrt_one_minus_alphas_cumprod[t] q_noise[j] (ddpm.py:1052-1058; q_coef = those two fp32 tables); temperature scales the step noise (ddim.py:255);
+    uncond + guidance_scale: classifier-free guidance (ddim.py:225-232); noise_dropout + dropout_keep: F.dropout on the step noise (ddim.py:256-257)."""
     tau = sched["ddim_timesteps"]
     coef = ddim_step_coeffs(sched)
     total = len(tau)
@@ -132,9 +137,15 @@ def ddim_sample(
             ti = int(tau[index])
             x = (q_coef[0][ti] * x0 + q_coef[1][ti] * q_noise[j]) * mask + (1.0 - mask) * x
         e = eps_model(torch.cat([x, cond], dim=1), t)
+        if uncond is not None and guidance_scale != 1.0:  # classifier-free guidance, ddim.py:225-232
+            e_u = eps_model(torch.cat([x, uncond], dim=1), t)
+            e = e_u + guidance_scale * (e - e_u)
         sa, s1m, sap, sdir, sig = (torch.tensor(float(v)) for v in coef[index])
         pred_x0 = (x - s1m * e) / sa
-        x = sap * pred_x0 + sdir * e + sig * step_noise[j] * temperature
+        nz = sig * step_noise[j] * temperature
+        if noise_dropout > 0.0:  # F.dropout(noise, p), ddim.py:256-257: kept elements scaled by 1 / (1 - p)
+            nz = nz * dropout_keep[j] / (1.0 - noise_dropout)
+        x = sap * pred_x0 + sdir * e + nz
         xs.append(x)
     return x, xs
 
@@ -158,6 +169,8 @@ def ddpm_sample(
     blend: str = "obsnet",
     temperature: float = 1.0,
     t_list: Optional[Sequence[int]] = None,
+    noise_dropout: float = 0.0,
+    dropout_keep: Optional[Sequence[torch.Tensor]] = None,
 ):
     """obsnet.py:500-564 over ddpm.py:1079-1167.  Returns (pred_x0_last, img_last, [img per step]).
     mask / x0: blend = "obsnet" (models/obsnet.py:545-547: BEFORE p_sample, img_orig = x0 at t == 0 else q_sample(x0, t - 1)) or "ldm"
@@ -184,7 +197,10 @@ def ddpm_sample(
         mean = S["posterior_mean_coef1"][i] * x_recon + S["posterior_mean_coef2"][i] * img  # :239-246
         logvar = S["posterior_log_variance_clipped"][i]
         nonzero = 0.0 if i == 0 else 1.0
-        img = mean + nonzero * (0.5 * logvar).exp() * (step_noise[j] * temperature)  # :1156-1167
+        nz = step_noise[j] * temperature
+        if noise_dropout > 0.0:  # ddpm.py:1158-1159
+            nz = nz * dropout_keep[j] / (1.0 - noise_dropout)
+        img = mean + nonzero * (0.5 * logvar).exp() * nz  # :1156-1167
         if mask is not None and blend == "ldm":
             img = q_sample(i, q_noise[j]) * mask + (1.0 - mask) * img
         pred_x0 = x_recon

@@ -221,7 +221,54 @@ def test_sampler_mask_x0_temperature_vs_reference_traces(dev, precision):
     with pytest.raises(ValueError):
         s.sample(50, 3, (3, 16, 16), cond, eta=0.0, x_T=x_T, verbose=False, seed=5, mask=T("mask1"))
     with pytest.raises(NotImplementedError):
-        s.sample(50, 3, (3, 16, 16), cond, eta=0.0, x_T=x_T, verbose=False, seed=5, unconditional_guidance_scale=2.0, unconditional_conditioning=cond)
+        s.sample(50, 3, (3, 16, 16), cond, eta=0.0, x_T=x_T, verbose=False, seed=5, score_corrector=object())
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx"])
+def test_guidance_and_noise_dropout_vs_reference_traces(dev, precision):
+    """[r6] classifier-free guidance (p_sample_ddim, ddim.py:225-232: a second forward per step on the unconditional conditioning, e = e_u + s (e_c - e_u))
+    and noise_dropout (ddim.py:256-257; ddpm.py:1158-1159: F.dropout on the step noise, keep masks injected) on the device loops against the reference's
+    own 50-step chains; graph replay == eager; Philox dropout runs and drops about p of the noise."""
+    from drmnet_amd import ops
+    from drmnet_amd.ddim import DDIMSampler
+
+    g = gold("sampler_guidance")
+    m = tiny_obsnet(dev).set_precision(precision)
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    cond, ucond, x_T, noise, keep = T("cond"), T("ucond"), T("x_T"), T("noise"), T("keep")
+    p, scale = float(g["p"]), float(g["scale"])
+    s = DDIMSampler(m)
+    kw = dict(eta=1.0, x_T=x_T, verbose=False, noise=noise)
+    tol = (2e-5, 2e-5) if precision != "f16mx" else (CONTRACT, CONTRACT)  # (first step, 50 steps; observed 1.7e-6 / 3.5e-5 at guidance scale 3)
+    x, inter = s.sample(50, 3, (3, 16, 16), cond, log_every_t=1, unconditional_guidance_scale=scale, unconditional_conditioning=ucond, **kw)
+    e1, e = rel_l2(inter["x_inter"][1].cpu(), g["cfg_first"]), rel_l2(x.cpu(), g["cfg_x"])
+    print(f"ddim guidance scale {scale} ({precision}): first step {e1:.2e}, 50 steps {e:.2e}")
+    assert e1 < tol[0] and e < tol[1]
+    # scale 1 or no unconditional conditioning: the plain chain (the reference's own condition, ddim.py:225)
+    plain, _ = s.sample(50, 3, (3, 16, 16), cond, log_every_t=0, **kw)
+    same, _ = s.sample(50, 3, (3, 16, 16), cond, log_every_t=0, unconditional_guidance_scale=1.0, unconditional_conditioning=ucond, **kw)
+    assert torch.equal(same, plain) and rel_l2(plain.cpu(), g["cfg_x"]) > 1e-2
+    xd, inter = s.sample(50, 3, (3, 16, 16), cond, log_every_t=1, noise_dropout=p, dropout_keep=keep, **kw)
+    e1, e = rel_l2(inter["x_inter"][1].cpu(), g["drop_first"]), rel_l2(xd.cpu(), g["drop_x"])
+    print(f"ddim noise_dropout {p} ({precision}): first step {e1:.2e}, 50 steps {e:.2e}")
+    assert e1 < tol[0] and e < (2e-5 if precision != "f16mx" else CONTRACT)
+    # ancestral loop: dropout with all-ones keep masks and p = 0.5 == the noise doubled (same kernel path, factor 1 / (1 - p))
+    a = m.p_sample_loop(cond, tuple(x_T.shape), x_T=x_T, verbose=False, start_T=6, noise=noise[:6], noise_dropout=0.5, dropout_keep=torch.ones_like(noise[:6]))
+    b = m.p_sample_loop(cond, tuple(x_T.shape), x_T=x_T, verbose=False, start_T=6, noise=noise[:6] * 2.0)
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6
+    ops.set_graph_replay(True)
+    try:
+        xg, _ = s.sample(50, 3, (3, 16, 16), cond, log_every_t=0, unconditional_guidance_scale=scale, unconditional_conditioning=ucond, **kw)
+        xdg, _ = s.sample(50, 3, (3, 16, 16), cond, log_every_t=0, noise_dropout=p, dropout_keep=keep, **kw)
+    finally:
+        ops.set_graph_replay(False)
+    assert torch.equal(xg, x) and torch.equal(xdg, xd)
+    # Philox keep masks: eta = 1 chain with p = 0.3 differs from the plain chain and stays finite; p out of range is rejected
+    xp, _ = s.sample(50, 3, (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, seed=5, noise_dropout=p, log_every_t=0)
+    xq, _ = s.sample(50, 3, (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, seed=5, log_every_t=0)
+    assert torch.isfinite(xp).all() and rel_l2(xp.cpu(), xq.cpu()) > 1e-3
+    with pytest.raises(ValueError):
+        s.sample(50, 3, (3, 16, 16), cond, eta=1.0, x_T=x_T, verbose=False, seed=5, noise_dropout=1.0)
 
 
 def test_ddim_timesteps_subset_vs_reference_trace(dev):

@@ -243,6 +243,26 @@ def test_sampler_mask_x0_temperature_traces():
         assert rel_l2(imgs[k], g["temp_x"][k]) < 5 * TOL
 
 
+def test_sampler_guidance_and_noise_dropout_traces():
+    """[r6] classifier-free guidance (ddim.py:225-232) and noise_dropout (ddim.py:256-257, ddpm.py:1158-1159) against the reference's own loops."""
+    g = gold("sampler_guidance")
+    Pu, _, _, tu, _ = tiny_nets()
+    S = osamp.ddpm_schedule(1000, 1e-4, 0.09)
+    d = osamp.ddim_schedule(S["alphas_cumprod"], 1000, 50, 1.0)
+    eps_model = lambda xc, t: ou.unet_forward(Pu, tu, xc, timesteps=t)
+    T = lambda k: torch.from_numpy(g[k])
+    x, xs = osamp.ddim_sample(eps_model, T("cond"), T("x_T"), T("noise"), d, uncond=T("ucond"), guidance_scale=float(g["scale"]))
+    assert rel_l2(xs[0], g["cfg_first"]) < TOL and rel_l2(x, g["cfg_x"]) < 5e-4  # (scale 3 amplifies the chain's rounding)
+    plain, _ = osamp.ddim_sample(eps_model, T("cond"), T("x_T"), T("noise"), d)
+    assert rel_l2(plain, g["cfg_x"]) > 1e-2  # guidance is not a no-op
+    x, xs = osamp.ddim_sample(eps_model, T("cond"), T("x_T"), T("noise"), d, noise_dropout=float(g["p"]), dropout_keep=T("keep"))
+    assert rel_l2(xs[0], g["drop_first"]) < TOL and rel_l2(x, g["drop_x"]) < 2e-4 and rel_l2(plain, g["drop_x"]) > 1e-2
+    _, _, imgs = osamp.ddpm_sample(eps_model, T("cond"), T("x_T"), T("noise"), S, t_list=[int(t) for t in g["ddpm_drop_t"]], noise_dropout=float(g["p"]),
+                                   dropout_keep=T("keep"))
+    for k in range(3):
+        assert rel_l2(imgs[k], g["ddpm_drop_x"][k]) < 5 * TOL
+
+
 def test_ddim_timesteps_subset_trace():
     """[r6] DDIMSampler.ddim_sampling(timesteps=30) (ddim.py:156-158): the first int(min(30 / 50, 1) * 50) - 1 = 29 entries of the 50-step schedule, run from
     index 28 down; the fixture also records that ddim_use_original_steps cannot run in the reference (AttributeError at ddim.py:242)."""

@@ -478,6 +478,66 @@ def make_sampler_masks():
     save("sampler_masks", **out)
 
 
+def make_sampler_guidance():
+    """Classifier-free guidance and noise_dropout, from the reference's own DDIM loop on the tiny ObsNet (B = 3 @16x16, eta = 1, 50 steps):
+    DDIMSampler.sample(unconditional_guidance_scale=3.0, unconditional_conditioning=<another refmap batch>) (ddim.py:225-232) and
+    DDIMSampler.sample(noise_dropout=0.3) with F.dropout's keep masks injected (ddim.py:256-257); LatentDiffusion.p_sample(noise_dropout=0.3) at three
+    timesteps (ddpm.py:1158-1159)."""
+    import ldm.models.diffusion.ddim as refddim
+    import ldm.models.diffusion.ddpm as refddpm
+
+    m, DDIM = tiny_obsnet()
+    B, h, w = 3, 16, 16
+    g = gen(83)
+    cond = synth.synth_refmaps(B, h, w, 98) * 2 - 1
+    ucond = synth.synth_refmaps(B, h, w, 97) * 2 - 1
+    x_T = torch.randn((B, 3, h, w), generator=g)
+    noise = torch.randn((50, B, 3, h, w), generator=g)
+    p = 0.3
+    keep = (torch.rand((50, B, 3, h, w), generator=g) >= p).float()
+    ctr = {"i": 0, "d": 0}
+
+    def noise_like(shape, device, repeat=False):
+        out = noise[ctr["i"]]
+        ctr["i"] += 1
+        return out
+
+    F = torch.nn.functional
+    orig_dropout = F.dropout
+
+    def dropout(x, p=0.5, training=True, inplace=False):
+        if not training:  # (the network's own nn.Dropout layers in eval mode)
+            return x
+        out = x * keep[ctr["d"]] / (1.0 - p)
+        ctr["d"] += 1
+        return out
+
+    o1, o2 = refddim.noise_like, refddpm.noise_like
+    refddim.noise_like = noise_like
+    refddpm.noise_like = noise_like
+    F.dropout = dropout
+    out = dict(cond=cond, ucond=ucond, x_T=x_T, noise=noise, keep=keep, p=p, scale=3.0)
+    try:
+        ctr.update(i=0, d=0)
+        x, inter = DDIM(m).sample(50, B, (3, h, w), cond, eta=1.0, x_T=x_T, verbose=False, log_every_t=1, unconditional_guidance_scale=3.0,
+                                  unconditional_conditioning=ucond)
+        out.update(cfg_x=x, cfg_first=inter["x_inter"][1])
+        ctr.update(i=0, d=0)
+        x, inter = DDIM(m).sample(50, B, (3, h, w), cond, eta=1.0, x_T=x_T, verbose=False, log_every_t=1, noise_dropout=p)
+        out.update(drop_x=x, drop_first=inter["x_inter"][1], drop_calls=ctr["d"])
+        ctr.update(i=0, d=0)
+        xs, img = [], x_T
+        for t in (5, 4, 0):
+            img = refddpm.LatentDiffusion.p_sample(m, img, cond, torch.full((B,), t, dtype=torch.long), clip_denoised=False, noise_dropout=p)
+            xs.append(img)
+        out.update(ddpm_drop_x=torch.stack(xs), ddpm_drop_t=np.asarray([5, 4, 0]))
+    finally:
+        refddim.noise_like, refddpm.noise_like = o1, o2
+        F.dropout = orig_dropout
+    print(f"  guidance / dropout: F.dropout calls in the 50-step chain {out['drop_calls']}")
+    save("sampler_guidance", **out)
+
+
 def make_ddim_variants():
     """DDIMSampler.ddim_sampling called directly with the schedule argument DDIMSampler.sample never passes (ddim.py:156-158): `timesteps` (a subset of
     the 50-step DDIM schedule: timesteps = 30 -> its first 29 entries), eta = 1.  Tiny ObsNet, B = 3 @16x16, draws injected."""
@@ -1119,6 +1179,7 @@ STEPS = {
     "obsnet_samplers": lambda oa: make_obsnet_samplers(),
     "sampler_masks": lambda oa: make_sampler_masks(),
     "ddim_variants": lambda oa: make_ddim_variants(),
+    "sampler_guidance": lambda oa: make_sampler_guidance(),
     "full": lambda oa: make_full_nets(oa),
     "full_samplers": lambda oa: make_full_samplers(),
     "transforms": lambda oa: make_transforms(),
