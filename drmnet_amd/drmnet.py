@@ -100,7 +100,9 @@ class DRMNet(nn.Module):
 
     def instantiate_brdf_model(self, config, basis_r0=None):
         """Reference renders basis_r0 (white envmap, BRDF z0) through Mitsuba (drmnet.py:328-347). Out of scope here:
-        basis_r0 is an optional input (ones by default) -- see DESIGN.md."""
+        basis_r0 is an optional input (ones by default) -- see DESIGN.md.  For the shipped z0 = [1, 1, 1, 1, 0, 1] (white, fully metallic,
+        roughness 0: Schlick F0 = base colour = 1) under the white environment the rendered quantity is analytically 1 on the sphere, so ones is
+        its noise-free value; any other z0 needs the rendered basis (first screen)."""
         self.renderer = instantiate_from_config(config) if config is not None else None
         if basis_r0 is None:
             basis_r0 = torch.ones(3, self.image_size, self.image_size)
